@@ -1,0 +1,230 @@
+"""ctypes binding of oracle/liboracle.so + a scene assembler on top of it.
+
+Test infrastructure: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg only.  `OracleRenderer` follows the call sequence of the
+reference's Renderer (add_blas -> add_blas_instance -> build_tlas,
+src/Renderer.cpp:756-899, 994-1015) using nothing but oracle functions.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracing_amd import _types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("rays", "tlas_interior", "tlas_leaf", "blas_interior", "blas_leaf",
+                 "tris_tested", "shaded_hits", "max_stack")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_ORACLE_DIR, "liboracle.so")
+    src = os.path.join(_ORACLE_DIR, "rt_oracle.cpp")
+    if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "liboracle.so"])
+    L = C.CDLL(so)
+    fp, vp, u32, u64 = C.POINTER(C.c_float), C.c_void_p, C.c_uint32, C.c_uint64
+    L.orc_mat4_inverse.argtypes = [vp, vp]
+    L.orc_mat4_mul.argtypes = [vp, vp, vp]
+    L.orc_trs.argtypes = [vp, vp, vp, vp]
+    L.orc_quat_angle_axis.argtypes = [C.c_float, vp, vp]
+    L.orc_camera_uniforms.argtypes = [vp, vp, vp, C.c_float, u32, u32, C.POINTER(T.CameraUniforms)]
+    L.orc_deindex.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    L.orc_build_blas.argtypes = [vp, vp, vp, vp, u32, u32]
+    L.orc_build_blas.restype = u32
+    L.orc_refit_blas.argtypes = [vp, u32, vp, vp]
+    L.orc_build_tlas.argtypes = [vp, vp, vp, u32, vp, vp]
+    L.orc_build_tlas.restype = u32
+    L.orc_wang_hash.argtypes = [C.POINTER(u32)]
+    L.orc_wang_hash.restype = u32
+    L.orc_rand.argtypes = [C.POINTER(u32)]
+    L.orc_rand.restype = C.c_float
+    L.orc_sincos.argtypes = [C.c_float, fp, fp]
+    L.orc_trace_closest.argtypes = [C.POINTER(T.SceneDesc), vp, u64, vp, u32, C.POINTER(Counters)]
+    L.orc_trace_brute.argtypes = [C.POINTER(T.SceneDesc), vp, u64, vp]
+    L.orc_render.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.CameraUniforms),
+                             C.POINTER(T.RenderParams), vp, C.POINTER(Counters), u32]
+    L.orc_gen_rays.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.CameraUniforms),
+                               C.POINTER(T.RenderParams), u32, vp, u64]
+    L.orc_gen_rays.restype = u64
+    _LIB = L
+    return L
+
+
+# ---- small math helpers over the oracle's glm restatements -----------------
+def f32a(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def mat4_inverse(m):
+    out = np.zeros(16, np.float32)
+    lib().orc_mat4_inverse(T.ptr(f32a(m)), T.ptr(out))
+    return out
+
+
+def angle_axis(angle, axis):
+    q = np.zeros(4, np.float32)
+    lib().orc_quat_angle_axis(np.float32(angle), T.ptr(f32a(axis)), T.ptr(q))
+    return q
+
+
+def trs(pos=(0, 0, 0), quat=(1, 0, 0, 0), scale=(1, 1, 1)):
+    out = np.zeros(16, np.float32)
+    lib().orc_trs(T.ptr(f32a(pos)), T.ptr(f32a(quat)), T.ptr(f32a(scale)), T.ptr(out))
+    return out
+
+
+def camera_uniforms(position, look_at, v_up, fov_deg, width, height):
+    cam = T.CameraUniforms()
+    lib().orc_camera_uniforms(T.ptr(f32a(position)), T.ptr(f32a(look_at)), T.ptr(f32a(v_up)),
+                              np.float32(fov_deg), width, height, C.byref(cam))
+    return cam
+
+
+def render_params(width, height, frame_index=0, sqrt_spp=1, max_depth=3,
+                  rng_mode=T.RNG_WANG, aabb_mode=T.AABB_DIV, accum_count=None,
+                  row_begin=0, row_end=0):
+    p = T.RenderParams()
+    p.image_width, p.image_height, p.frame_index = width, height, frame_index
+    p.accum_count = frame_index if accum_count is None else accum_count
+    p.sqrt_spp, p.max_depth, p.rng_mode, p.aabb_mode = sqrt_spp, max_depth, rng_mode, aabb_mode
+    p.row_begin, p.row_end = row_begin, row_end
+    return p
+
+
+class OracleRenderer:
+    """Scene owner restating Renderer::add_blas / add_blas_instance /
+    build_tlas with zero-based pool offsets and
+    ascending-id TLAS leaf order (App. C #19)."""
+
+    def __init__(self):
+        self.geom = np.zeros(0, T.geom_dtype)
+        self.shading = np.zeros(0, T.shading_dtype)
+        self.centroids = np.zeros((0, 3), np.float32)
+        self.tri_ids = np.zeros(0, np.uint32)
+        self.nodes = np.zeros(0, T.bvh_node_dtype)
+        self.blas = np.zeros(0, T.blas_dtype)
+        self.instances = np.zeros(0, T.instance_dtype)
+        self.lamberts, self.metals, self.dielectrics, self.emissives = [], [], [], []
+        self.textures, self.texels = [], bytearray()
+        self.default_material = self.add_lambert_material((0.7, 0.7, 0.7))  # Renderer.cpp:405
+
+    # materials (Renderer.cpp:686-729)
+    def add_lambert_texture(self, width, height, pixels_rgba8):
+        px = np.ascontiguousarray(pixels_rgba8, np.uint8).reshape(-1)
+        assert px.size == width * height * 4
+        self.textures.append((len(self.texels), width, height, 0))
+        self.texels += px.tobytes()
+        self.lamberts.append(len(self.textures) - 1)
+        return (len(self.lamberts) - 1, T.MATERIAL_LAMBERT)
+
+    def add_lambert_material(self, albedo):
+        c = np.clip(f32a(albedo), np.float32(0), np.float32(1))
+        px = (c * np.float32(255.0)).astype(np.uint8)  # truncation, Renderer.cpp:696-698
+        return self.add_lambert_texture(1, 1, [px[0], px[1], px[2], 255])
+
+    def add_metal_material(self, albedo, fuzz):
+        self.metals.append([albedo[0], albedo[1], albedo[2], fuzz])
+        return (len(self.metals) - 1, T.MATERIAL_METAL)
+
+    def add_dielectric_material(self, ri):
+        self.dielectrics.append(ri)
+        return (len(self.dielectrics) - 1, T.MATERIAL_DIELECTRIC)
+
+    def add_emissive_material(self, intensity):
+        self.emissives.append([intensity[0], intensity[1], intensity[2], 1.0])
+        return (len(self.emissives) - 1, T.MATERIAL_EMISSIVE)
+
+    def add_blas(self, positions, normals, uvs, indices):
+        L = lib()
+        positions, normals, uvs = f32a(positions).reshape(-1, 3), f32a(normals).reshape(-1, 3), f32a(uvs).reshape(-1, 2)
+        indices = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        n = indices.size // 3
+        base = len(self.tri_ids)
+        self.geom = np.concatenate([self.geom, np.zeros(n, T.geom_dtype)])
+        self.shading = np.concatenate([self.shading, np.zeros(n, T.shading_dtype)])
+        self.centroids = np.concatenate([self.centroids, np.zeros((n, 3), np.float32)])
+        self.tri_ids = np.concatenate([self.tri_ids, np.zeros(n, np.uint32)])
+        L.orc_deindex(T.ptr(positions), T.ptr(normals), T.ptr(uvs), T.ptr(indices), indices.size, base,
+                      T.ptr(self.geom), T.ptr(self.shading), T.ptr(self.centroids), T.ptr(self.tri_ids))
+        scratch = np.zeros(max(2 * n - 1, 1), T.bvh_node_dtype)
+        count = L.orc_build_blas(T.ptr(scratch), T.ptr(self.geom), T.ptr(self.centroids),
+                                 T.ptr(self.tri_ids), n, base)
+        rec = np.zeros(1, T.blas_dtype)
+        rec["bvh_nodes_offset"], rec["nodes_count"], rec["tri_count"] = len(self.nodes), count, n
+        self.nodes = np.concatenate([self.nodes, scratch[:count]])
+        self.blas = np.concatenate([self.blas, rec])
+        return len(self.blas) - 1
+
+    def add_blas_instance(self, blas_index, transform, material):
+        inst = np.zeros(1, T.instance_dtype)
+        inst["transform"][0] = f32a(transform).reshape(16)
+        inst["inv_transform"][0] = mat4_inverse(transform)  # BVHNode.cpp:179-182
+        inst["mat_index"], inst["mat_type"], inst["blas_id"] = material[0], material[1], blas_index
+        self.instances = np.concatenate([self.instances, inst])
+        return len(self.instances) - 1
+
+    def set_blas_instance_transform(self, inst_id, transform):
+        self.instances["transform"][inst_id] = f32a(transform).reshape(16)
+        self.instances["inv_transform"][inst_id] = mat4_inverse(transform)
+
+    def build(self, instance_ids=None):
+        """build_tlas (Renderer.cpp:994-1015) and publish the arrays."""
+        n = len(self.instances)
+        ids = np.arange(n, dtype=np.uint32) if instance_ids is None else np.ascontiguousarray(instance_ids, np.uint32)
+        tlas = np.zeros(max(2 * len(ids), 1), T.tlas_node_dtype)
+        count = lib().orc_build_tlas(T.ptr(tlas), T.ptr(self.instances), T.ptr(ids), len(ids),
+                                     T.ptr(self.blas), T.ptr(self.nodes))
+        tex = np.array(self.textures, dtype=T.texture_dtype) if self.textures else np.zeros(0, T.texture_dtype)
+        return T.SceneArrays(self.geom, self.shading, self.tri_ids, self.nodes, self.blas, self.instances,
+                             tlas, count, self.lamberts, self.metals if self.metals else None,
+                             self.dielectrics if self.dielectrics else None,
+                             self.emissives if self.emissives else None, tex,
+                             np.frombuffer(bytes(self.texels), np.uint8))
+
+
+def trace_closest(scene, rays, aabb_mode=T.AABB_DIV, counters=None):
+    rays = np.ascontiguousarray(rays, T.ray_dtype)
+    hits = np.zeros(len(rays), T.hit_dtype)
+    d = scene.desc()
+    lib().orc_trace_closest(C.byref(d), T.ptr(rays), len(rays), T.ptr(hits), aabb_mode,
+                            C.byref(counters) if counters is not None else None)
+    return hits
+
+
+def trace_brute(scene, rays):
+    rays = np.ascontiguousarray(rays, T.ray_dtype)
+    hits = np.zeros(len(rays), T.hit_dtype)
+    d = scene.desc()
+    lib().orc_trace_brute(C.byref(d), T.ptr(rays), len(rays), T.ptr(hits))
+    return hits
+
+
+def render(scene, cam, params, accum=None, counters=None, nthreads=1):
+    if accum is None:
+        accum = np.zeros((params.image_height, params.image_width, 4), np.float32)
+    d = scene.desc()
+    lib().orc_render(C.byref(d), C.byref(cam), C.byref(params), T.ptr(accum),
+                     C.byref(counters) if counters is not None else None, nthreads)
+    return accum
+
+
+def gen_rays(scene, cam, params, bounce, cap=None):
+    cap = params.image_width * params.image_height if cap is None else cap
+    rays = np.zeros(cap, T.ray_dtype)
+    d = scene.desc()
+    n = lib().orc_gen_rays(C.byref(d), C.byref(cam), C.byref(params), bounce, T.ptr(rays), cap)
+    return rays[:n]
