@@ -1,0 +1,105 @@
+/* rt_hip.h — C ABI of librt_hip.so: the MI355X (gfx950) render path.
+ *
+ * This is the drop-in boundary.  It replaces everything the reference does
+ * from `vkCmdDispatch` downwards (src/Renderer.cpp:615-651 and the Slang kernel
+ * Assets/Shaders/RayTracing.slang:62-181) plus the device-buffer staging of
+ * src/Renderer.cpp:790-853, 867-868, 1007-1011.  Inputs are the reference's own
+ * host arrays (rt_types.h); the library flattens them into its device layout.
+ *
+ * Conventions: every function returns 0 on success or a negative rt_status;
+ * the message of the last failure on the calling thread is available from
+ * rt_last_error_string().  A context belongs to one GPU and one host thread.
+ * rt_render / rt_trace_closest_device are asynchronous on the context's HIP
+ * stream; rt_sync, rt_read_accum, rt_trace_closest and rt_get_stats wait.
+ * The library fails (RT_ERR_NO_DEVICE) when no HIP device is present — there
+ * is no CPU fallback.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = -1,
+  RT_ERR_NO_DEVICE = -2,
+  RT_ERR_HIP = -3,
+  RT_ERR_OUT_OF_MEMORY = -4,
+  RT_ERR_NO_SCENE = -5,
+  RT_ERR_UNSUPPORTED = -6 /* e.g. tree deeper than the traversal stack */
+};
+
+typedef struct rt_stats {
+  uint64_t rays_traced;   /* closest-hit queries since rt_reset_stats (primary + bounces) */
+  double last_kernel_ms;  /* HIP-event time of the most recent kernel launch */
+  double total_kernel_ms; /* sum over launches since rt_reset_stats */
+  uint64_t launches;
+  uint32_t stack_depth_needed; /* TLAS depth + 1 + deepest BLAS of the scene */
+  uint32_t reserved;
+  uint64_t device_bytes; /* scene bytes resident in HBM */
+} rt_stats;
+
+/* replaces Renderer::init's device/pipeline set-up, src/Renderer.cpp:215-410 */
+int rt_create(int device_id, rt_ctx **out_ctx);
+/* replaces Renderer::shutdown, src/Renderer.cpp:412-460 */
+int rt_destroy(rt_ctx *ctx);
+
+/* replaces the staging of the 11 UniformData arrays, src/Renderer.cpp:790-853
+ * (add_blas), :867-868 (add_blas_instance), :1007-1011 (build_tlas) and
+ * src/Material.cpp:196-201.  Copies; the caller may free its arrays after. */
+int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
+/* replaces the per-frame instance/TLAS restaging after
+ * set_blas_instance_transform, src/Renderer.cpp:901-916, 994-1015. */
+int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances,
+                        uint32_t instance_count, const rt_tlas_node *tlas_nodes,
+                        uint32_t tlas_node_count);
+
+/* replaces the uniform-buffer memcpy, src/Renderer.cpp:532-561 */
+int rt_set_camera(rt_ctx *ctx, const rt_camera_uniforms *camera);
+
+/* replaces create_output_image / resize, src/Renderer.cpp:462-486, 654-684.
+ * Allocates (or re-uses) a W*H rgba32f accumulation image and zeroes it. */
+int rt_resize(rt_ctx *ctx, uint32_t width, uint32_t height);
+/* Renders into caller-owned device memory (W*H*16 bytes, e.g. a tensor that a
+ * collective will read) instead of the internal image; NULL reverts. */
+int rt_bind_accum(rt_ctx *ctx, void *device_rgba32f, uint32_t width,
+                  uint32_t height);
+/* replaces vkCmdClearColorImage on frame 0, src/Renderer.cpp:584-606 */
+int rt_clear_accum(rt_ctx *ctx);
+
+/* replaces push constants + vkCmdDispatch, src/Renderer.cpp:619-648:
+ * one launch of the path-tracing megakernel (compute_main). */
+int rt_render(rt_ctx *ctx, const rt_render_params *params);
+
+/* Test hook: intersect_tlas (TLAS.slang:14-67) over an explicit ray batch.
+ * Host-pointer form copies in and out and waits; device form is async. */
+int rt_trace_closest(rt_ctx *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits,
+                     uint32_t aabb_mode);
+int rt_trace_closest_device(rt_ctx *ctx, const void *device_rays, uint64_t n,
+                            void *device_hits, uint32_t aabb_mode);
+
+/* The reference has no read-back (the image is only sampled by its blit
+ * shader, src/PathTracer.cpp:491); these serve the CLI, tests and bench. */
+int rt_read_accum(rt_ctx *ctx, float *host_rgba32f);
+int rt_accum_device_ptr(rt_ctx *ctx, void **out_device_ptr);
+int rt_sync(rt_ctx *ctx);
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+int rt_reset_stats(rt_ctx *ctx);
+/* 0: reference-structured kernel (one lane per pixel, nested loops);
+ * 1: persistent waves with path regeneration.  Same results bit for bit. */
+int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
+
+const char *rt_last_error_string(void);
+/* number of HIP devices visible (0 on a CPU-only machine; never fails) */
+int rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,157 @@
+"""ctypes binding of librt_hip.so (include/rt_hip.h).
+
+The library is built in-tree by __graft_entry__.build() / raytracing_amd/csrc/Makefile.
+Loading fails loudly when it is missing; there is no Python or CPU fallback for
+any entry point.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _types as T
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librt_hip.so")
+
+# every symbol include/rt_hip.h declares
+SYMBOLS = [
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
+    "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
+    "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
+    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_last_error_string",
+    "rt_device_count",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_traced", C.c_uint64), ("last_kernel_ms", C.c_double),
+                ("total_kernel_ms", C.c_double), ("launches", C.c_uint64),
+                ("stack_depth_needed", C.c_uint32), ("reserved", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librt_hip error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                          "(make -C raytracing_amd/csrc); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_upload_scene.argtypes = [vp, C.POINTER(T.SceneDesc)]
+    L.rt_update_instances.argtypes = [vp, vp, u32, vp, u32]
+    L.rt_set_camera.argtypes = [vp, C.POINTER(T.CameraUniforms)]
+    L.rt_resize.argtypes = [vp, u32, u32]
+    L.rt_bind_accum.argtypes = [vp, vp, u32, u32]
+    L.rt_clear_accum.argtypes = [vp]
+    L.rt_render.argtypes = [vp, C.POINTER(T.RenderParams)]
+    L.rt_trace_closest.argtypes = [vp, vp, u64, vp, u32]
+    L.rt_trace_closest_device.argtypes = [vp, vp, u64, vp, u32]
+    L.rt_read_accum.argtypes = [vp, vp]
+    L.rt_accum_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.rt_sync.argtypes = [vp]
+    L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rt_reset_stats.argtypes = [vp]
+    L.rt_set_kernel_variant.argtypes = [vp, u32]
+    L.rt_last_error_string.restype = C.c_char_p
+    L.rt_device_count.restype = C.c_int
+    for name in SYMBOLS:
+        if name not in ("rt_last_error_string",):
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, lib().rt_last_error_string().decode(errors="replace"))
+
+
+class HipContext:
+    """One rt_ctx: one GPU, one host thread."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().rt_create(device, C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, scene):
+        """scene: _types.SceneArrays (the 11 reference arrays + textures)."""
+        d = scene.desc()
+        _check(lib().rt_upload_scene(self._h, C.byref(d)))
+
+    def update_instances(self, instances, tlas_nodes, tlas_node_count):
+        _check(lib().rt_update_instances(self._h, T.ptr(instances), len(instances),
+                                         T.ptr(tlas_nodes), int(tlas_node_count)))
+
+    def set_camera(self, cam):
+        _check(lib().rt_set_camera(self._h, C.byref(cam)))
+
+    def resize(self, width, height):
+        _check(lib().rt_resize(self._h, width, height))
+
+    def bind_accum(self, device_ptr, width, height):
+        _check(lib().rt_bind_accum(self._h, C.c_void_p(device_ptr), width, height))
+
+    def clear_accum(self):
+        _check(lib().rt_clear_accum(self._h))
+
+    def render(self, params):
+        _check(lib().rt_render(self._h, C.byref(params)))
+
+    def trace_closest(self, rays, aabb_mode=T.AABB_DIV):
+        rays = np.ascontiguousarray(rays, T.ray_dtype)
+        hits = np.zeros(len(rays), T.hit_dtype)
+        _check(lib().rt_trace_closest(self._h, T.ptr(rays), len(rays), T.ptr(hits), aabb_mode))
+        return hits
+
+    def trace_closest_device(self, rays_ptr, n, hits_ptr, aabb_mode=T.AABB_DIV):
+        _check(lib().rt_trace_closest_device(self._h, C.c_void_p(rays_ptr), n, C.c_void_p(hits_ptr), aabb_mode))
+
+    def read_accum(self, width, height):
+        out = np.zeros((height, width, 4), np.float32)
+        _check(lib().rt_read_accum(self._h, T.ptr(out)))
+        return out
+
+    def accum_device_ptr(self):
+        p = C.c_void_p()
+        _check(lib().rt_accum_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def sync(self):
+        _check(lib().rt_sync(self._h))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().rt_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        _check(lib().rt_reset_stats(self._h))
+
+    def set_kernel_variant(self, v):
+        _check(lib().rt_set_kernel_variant(self._h, v))

@@ -1,0 +1,536 @@
+// rt_hip_api.cpp — the C ABI of include/rt_hip.h: context, HBM residency of the
+// flattened scene, launches, statistics.  No CPU fallback: without a HIP device
+// rt_create fails.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_flatten.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,            \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+  } while (0)
+
+template <typename T> struct DevBuf {
+  T *ptr = nullptr;
+  size_t count = 0; // capacity in elements
+  hipError_t reserve(size_t n) {
+    if (n <= count && ptr)
+      return hipSuccess;
+    if (ptr)
+      (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)&ptr, bytes);
+    if (e == hipSuccess)
+      count = n ? n : 1;
+    return e;
+  }
+  void release() {
+    if (ptr)
+      (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+} // namespace
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // scene in HBM
+  DevBuf<rt_dev_pair> pairs;
+  DevBuf<rt_dev_tri> tris;
+  DevBuf<rt_dev_inst> inst_trace;
+  DevBuf<rt_blas_instance> instances;
+  DevBuf<rt_triangle_shading> shading;
+  DevBuf<uint32_t> lamberts;
+  DevBuf<float4> metals;
+  DevBuf<float> dielectrics;
+  DevBuf<float4> emissives;
+  DevBuf<rt_texture_desc> textures;
+  DevBuf<uint8_t> texels;
+  DevBuf<unsigned long long> counter;
+  rt_dev_scene dev{};
+  bool have_scene = false;
+  // host-side remnants needed by rt_update_instances
+  rt_flat_scene flat;
+  uint32_t blas_count = 0;
+  rt_scene_desc material_counts{}; // counts only (pointers cleared)
+  std::vector<rt_lambert> h_lamberts;
+  std::vector<rt_texture_desc> h_textures;
+  uint64_t texel_bytes = 0;
+  // image
+  DevBuf<float> accum_own;
+  float *accum = nullptr;
+  uint32_t width = 0, height = 0;
+  bool accum_bound = false;
+  rt_camera_uniforms camera{};
+  bool have_camera = false;
+  uint32_t variant = 0;
+  // timing
+  std::vector<EventPair> pending, free_events;
+  double total_ms = 0.0, last_ms = 0.0;
+  uint64_t launches = 0;
+};
+
+namespace {
+
+int drain_events(rt_ctx *ctx) {
+  for (EventPair &p : ctx->pending) {
+    HIP_TRY(hipEventSynchronize(p.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+    ctx->last_ms = ms;
+    ctx->total_ms += ms;
+    ctx->free_events.push_back(p);
+  }
+  ctx->pending.clear();
+  return RT_OK;
+}
+
+int begin_timed(rt_ctx *ctx, EventPair &ev) {
+  if (ctx->pending.size() >= 1024) {
+    int rc = drain_events(ctx);
+    if (rc != RT_OK)
+      return rc;
+  }
+  if (!ctx->free_events.empty()) {
+    ev = ctx->free_events.back();
+    ctx->free_events.pop_back();
+  } else {
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+  }
+  HIP_TRY(hipEventRecord(ev.a, ctx->stream));
+  return RT_OK;
+}
+
+int end_timed(rt_ctx *ctx, const EventPair &ev) {
+  HIP_TRY(hipEventRecord(ev.b, ctx->stream));
+  ctx->pending.push_back(ev);
+  ++ctx->launches;
+  return RT_OK;
+}
+
+template <typename T>
+int upload(rt_ctx *ctx, DevBuf<T> &buf, const void *src, size_t n) {
+  HIP_TRY(buf.reserve(n));
+  if (n)
+    HIP_TRY(hipMemcpyAsync(buf.ptr, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return RT_OK;
+}
+
+// [blas pairs | tlas pairs] with TLAS-internal references rebased.
+int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, uint32_t n_inst) {
+  rt_flat_scene &f = ctx->flat;
+  const uint32_t base = (uint32_t)f.blas_pairs.size();
+  std::vector<rt_dev_pair> all(f.blas_pairs);
+  all.reserve(all.size() + f.tlas_pairs.size());
+  for (rt_dev_pair p : f.tlas_pairs) {
+    if (!(p.ref0 & RT_REF_LEAF))
+      p.ref0 += base;
+    if (!(p.ref1 & RT_REF_LEAF))
+      p.ref1 += base;
+    all.push_back(p);
+  }
+  if (all.size() >= RT_REF_INST)
+    return fail(RT_ERR_UNSUPPORTED, "too many interior nodes for a 30-bit reference");
+  if (f.stack_needed > RT_MAX_STACK)
+    return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of " + std::to_string(f.stack_needed) +
+                                        " entries; the kernels hold " + std::to_string(RT_MAX_STACK));
+  int rc;
+  if ((rc = upload(ctx, ctx->pairs, all.data(), all.size())) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->inst_trace, f.insts.data(), f.insts.size())) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->instances, instances, n_inst)) != RT_OK)
+    return rc;
+  // the staging vector dies at return: finish the copies first
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->dev.pairs = ctx->pairs.ptr;
+  ctx->dev.inst_trace = ctx->inst_trace.ptr;
+  ctx->dev.instances = ctx->instances.ptr;
+  uint32_t root = f.root_ref;
+  if (root != RT_REF_NONE && !(root & RT_REF_LEAF))
+    root += base;
+  ctx->dev.root_ref = root;
+  return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error_string(void) { return g_last_error.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int rt_create(int device_id, rt_ctx **out_ctx) {
+  if (!out_ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_create: out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device (this library has no CPU path)");
+  if (device_id < 0 || device_id >= n)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_create: device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  rt_ctx *ctx = new rt_ctx();
+  ctx->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess)
+    e = ctx->counter.reserve(1);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(RT_ERR_HIP, std::string("rt_create: ") + hipGetErrorString(e));
+  }
+  ctx->dev.root_ref = RT_REF_NONE;
+  *out_ctx = ctx;
+  return RT_OK;
+}
+
+int rt_destroy(rt_ctx *ctx) {
+  if (!ctx)
+    return RT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (EventPair &p : ctx->pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (EventPair &p : ctx->free_events) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  ctx->pairs.release();
+  ctx->tris.release();
+  ctx->inst_trace.release();
+  ctx->instances.release();
+  ctx->shading.release();
+  ctx->lamberts.release();
+  ctx->metals.release();
+  ctx->dielectrics.release();
+  ctx->emissives.release();
+  ctx->textures.release();
+  ctx->texels.release();
+  ctx->counter.release();
+  ctx->accum_own.release();
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *sc) {
+  if (!ctx || !sc)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: NULL argument");
+  if ((sc->tri_capacity && (!sc->tri_geom || !sc->tri_shading || !sc->tri_ids)) ||
+      (sc->bvh_node_count && !sc->bvh_nodes) || (sc->blas_count && !sc->blas) ||
+      (sc->instance_count && !sc->instances) || (sc->tlas_node_count && !sc->tlas_nodes) ||
+      (sc->lambert_count && !sc->lamberts) || (sc->metal_count && !sc->metals) ||
+      (sc->dielectric_count && !sc->dielectrics) || (sc->emissive_count && !sc->emissives) ||
+      (sc->texture_count && !sc->textures) || (sc->texel_bytes && !sc->texels))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: a non-empty array has a NULL pointer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->have_scene = false;
+  std::string err;
+  if (!rt_flatten_blas(sc, ctx->flat, err))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: " + err);
+  if (!rt_flatten_tlas(sc->instances, sc->instance_count, sc->tlas_nodes, sc->tlas_node_count,
+                       sc->blas_count, ctx->flat, err))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: " + err);
+  if (!rt_validate_materials(sc, sc->instances, sc->instance_count, ctx->flat.inst_live, err))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: " + err);
+  ctx->blas_count = sc->blas_count;
+  int rc;
+  if ((rc = upload(ctx, ctx->tris, ctx->flat.tris.data(), ctx->flat.tris.size())) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->shading, sc->tri_shading, sc->tri_capacity)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->lamberts, sc->lamberts, sc->lambert_count)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->metals, sc->metals, sc->metal_count)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->dielectrics, sc->dielectrics, sc->dielectric_count)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->emissives, sc->emissives, sc->emissive_count)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->textures, sc->textures, sc->texture_count)) != RT_OK)
+    return rc;
+  if ((rc = upload(ctx, ctx->texels, sc->texels, (size_t)sc->texel_bytes)) != RT_OK)
+    return rc;
+  ctx->dev.tris = ctx->tris.ptr;
+  ctx->dev.shading = ctx->shading.ptr;
+  ctx->dev.lamberts = ctx->lamberts.ptr;
+  ctx->dev.metals = ctx->metals.ptr;
+  ctx->dev.dielectrics = ctx->dielectrics.ptr;
+  ctx->dev.emissives = ctx->emissives.ptr;
+  ctx->dev.textures = ctx->textures.ptr;
+  ctx->dev.texels = ctx->texels.ptr;
+  if ((rc = upload_pairs_and_instances(ctx, sc->instances, sc->instance_count)) != RT_OK)
+    return rc;
+  // keep what rt_update_instances must re-validate against
+  ctx->material_counts = *sc;
+  ctx->h_lamberts.assign(sc->lamberts, sc->lamberts + sc->lambert_count);
+  ctx->h_textures.assign(sc->textures, sc->textures + sc->texture_count);
+  ctx->material_counts.lamberts = ctx->h_lamberts.data();
+  ctx->material_counts.textures = ctx->h_textures.data();
+  ctx->texel_bytes = sc->texel_bytes;
+  ctx->flat.tris.clear();
+  ctx->flat.tris.shrink_to_fit(); // resident in HBM now
+  ctx->have_scene = true;
+  return RT_OK;
+}
+
+int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances, uint32_t instance_count,
+                        const rt_tlas_node *tlas_nodes, uint32_t tlas_node_count) {
+  if (!ctx || (instance_count && !instances) || (tlas_node_count && !tlas_nodes))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: NULL argument");
+  if (!ctx->have_scene)
+    return fail(RT_ERR_NO_SCENE, "rt_update_instances: no scene uploaded");
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::string err;
+  if (!rt_flatten_tlas(instances, instance_count, tlas_nodes, tlas_node_count, ctx->blas_count,
+                       ctx->flat, err))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
+  ctx->material_counts.texture_count = 0; // textures were validated at upload
+  if (!rt_validate_materials(&ctx->material_counts, instances, instance_count, ctx->flat.inst_live, err)) {
+    ctx->material_counts.texture_count = (uint32_t)ctx->h_textures.size();
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
+  }
+  ctx->material_counts.texture_count = (uint32_t)ctx->h_textures.size();
+  // kernels in flight still read the old arrays
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return upload_pairs_and_instances(ctx, instances, instance_count);
+}
+
+int rt_set_camera(rt_ctx *ctx, const rt_camera_uniforms *camera) {
+  if (!ctx || !camera)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_camera: NULL argument");
+  ctx->camera = *camera;
+  ctx->have_camera = true;
+  return RT_OK;
+}
+
+int rt_resize(rt_ctx *ctx, uint32_t width, uint32_t height) {
+  if (!ctx || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 31))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_resize: bad extent");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx->accum_own.reserve((size_t)width * height * 4));
+  ctx->accum = ctx->accum_own.ptr;
+  ctx->accum_bound = false;
+  ctx->width = width;
+  ctx->height = height;
+  return rt_clear_accum(ctx);
+}
+
+int rt_bind_accum(rt_ctx *ctx, void *device_rgba32f, uint32_t width, uint32_t height) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_bind_accum: NULL context");
+  if (!device_rgba32f) {
+    ctx->accum = ctx->accum_own.ptr;
+    ctx->accum_bound = false;
+    if (!ctx->accum)
+      ctx->width = ctx->height = 0;
+    return RT_OK;
+  }
+  if (width == 0 || height == 0 || ((uintptr_t)device_rgba32f & 15u))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_bind_accum: bad extent or pointer not 16-byte aligned");
+  ctx->accum = static_cast<float *>(device_rgba32f);
+  ctx->accum_bound = true;
+  ctx->width = width;
+  ctx->height = height;
+  return RT_OK;
+}
+
+int rt_clear_accum(rt_ctx *ctx) {
+  if (!ctx || !ctx->accum)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_clear_accum: no image");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
+  return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, const rt_render_params *params) {
+  if (!ctx || !params)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
+  if (!ctx->have_scene)
+    return fail(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+  if (!ctx->have_camera)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: no camera set");
+  rt_render_params pc = *params;
+  if (pc.image_width == 0 || pc.image_height == 0 || pc.sqrt_spp == 0 || pc.sqrt_spp > 4096 ||
+      pc.rng_mode > RT_RNG_PCG || pc.aabb_mode > RT_AABB_RCP)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: bad parameters");
+  if (!ctx->accum || ctx->width != pc.image_width || ctx->height != pc.image_height) {
+    if (ctx->accum_bound)
+      return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: extent differs from the bound image");
+    int rc = rt_resize(ctx, pc.image_width, pc.image_height);
+    if (rc != RT_OK)
+      return rc;
+  }
+  if (pc.row_begin == 0 && pc.row_end == 0)
+    pc.row_end = pc.image_height;
+  if (pc.row_end > pc.image_height)
+    pc.row_end = pc.image_height;
+  if (pc.row_begin >= pc.row_end)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty row range");
+  HIP_TRY(hipSetDevice(ctx->device));
+  EventPair ev;
+  int rc = begin_timed(ctx, ev);
+  if (rc != RT_OK)
+    return rc;
+  HIP_TRY(rt_launch_render(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
+                           ctx->stream));
+  return end_timed(ctx, ev);
+}
+
+int rt_trace_closest_device(rt_ctx *ctx, const void *device_rays, uint64_t n, void *device_hits,
+                            uint32_t aabb_mode) {
+  if (!ctx || (n && (!device_rays || !device_hits)) || aabb_mode > RT_AABB_RCP)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest_device: bad argument");
+  if (!ctx->have_scene)
+    return fail(RT_ERR_NO_SCENE, "rt_trace_closest: no scene uploaded");
+  if (((uintptr_t)device_rays & 15u) || ((uintptr_t)device_hits & 15u))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest_device: buffers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  EventPair ev;
+  int rc = begin_timed(ctx, ev);
+  if (rc != RT_OK)
+    return rc;
+  HIP_TRY(rt_launch_trace(ctx->dev, static_cast<const rt_ray *>(device_rays), n,
+                          static_cast<rt_hit *>(device_hits), aabb_mode, ctx->counter.ptr, ctx->stream));
+  return end_timed(ctx, ev);
+}
+
+int rt_trace_closest(rt_ctx *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, uint32_t aabb_mode) {
+  if (!ctx || (n && (!rays || !hits)))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_trace_closest: NULL argument");
+  if (n == 0)
+    return RT_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  rt_ray *d_rays = nullptr;
+  rt_hit *d_hits = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(rt_ray)));
+  hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(rt_hit));
+  if (e != hipSuccess) {
+    (void)hipFree(d_rays);
+    return fail(RT_ERR_OUT_OF_MEMORY, "rt_trace_closest: hipMalloc failed");
+  }
+  int rc = RT_OK;
+  e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    rc = rt_trace_closest_device(ctx, d_rays, n, d_hits, aabb_mode);
+  if (e == hipSuccess && rc == RT_OK)
+    e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t es = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hits);
+  if (rc != RT_OK)
+    return rc;
+  if (e != hipSuccess || es != hipSuccess)
+    return fail(RT_ERR_HIP, std::string("rt_trace_closest: ") + hipGetErrorString(e != hipSuccess ? e : es));
+  return RT_OK;
+}
+
+int rt_read_accum(rt_ctx *ctx, float *host_rgba32f) {
+  if (!ctx || !host_rgba32f || !ctx->accum)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_read_accum: no image or NULL destination");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(host_rgba32f, ctx->accum, (size_t)ctx->width * ctx->height * 16,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_accum_device_ptr(rt_ctx *ctx, void **out) {
+  if (!ctx || !out)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_accum_device_ptr: NULL argument");
+  *out = ctx->accum;
+  return RT_OK;
+}
+
+int rt_sync(rt_ctx *ctx) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_sync: NULL context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
+  if (!ctx || !out)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_get_stats: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int rc = drain_events(ctx);
+  if (rc != RT_OK)
+    return rc;
+  unsigned long long rays = 0;
+  HIP_TRY(hipMemcpy(&rays, ctx->counter.ptr, sizeof rays, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->rays_traced = rays;
+  out->last_kernel_ms = ctx->last_ms;
+  out->total_kernel_ms = ctx->total_ms;
+  out->launches = ctx->launches;
+  out->stack_depth_needed = ctx->flat.stack_needed;
+  out->device_bytes = ctx->pairs.count * sizeof(rt_dev_pair) + ctx->tris.count * sizeof(rt_dev_tri) +
+                      ctx->inst_trace.count * sizeof(rt_dev_inst) +
+                      ctx->instances.count * sizeof(rt_blas_instance) +
+                      ctx->shading.count * sizeof(rt_triangle_shading) + ctx->texels.count;
+  return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx *ctx) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_reset_stats: NULL context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int rc = drain_events(ctx);
+  if (rc != RT_OK)
+    return rc;
+  HIP_TRY(hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream));
+  ctx->total_ms = ctx->last_ms = 0.0;
+  ctx->launches = 0;
+  return RT_OK;
+}
+
+int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
+  if (!ctx || variant > 1)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
+  ctx->variant = variant;
+  return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,35 @@
+// rt_kernels.h — kernel argument block and launch entry points shared by
+// rt_kernels.hip (device code) and rt_hip_api.cpp (the C ABI).
+#ifndef RT_KERNELS_H
+#define RT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_types.h"
+#include "rt_device_layout.h"
+
+// Device pointers of the flattened scene; passed to kernels by value.
+struct rt_dev_scene {
+  const rt_dev_pair *pairs;          // TLAS + BLAS interior records
+  const rt_dev_tri *tris;            // leaf-ordered triangles
+  const rt_dev_inst *inst_trace;     // per instance: inv_transform columns + BLAS root
+  const rt_blas_instance *instances; // reference layout, read once per shaded hit
+  const rt_triangle_shading *shading; // reference layout, indexed by triangle id
+  const uint32_t *lamberts;
+  const float4 *metals;
+  const float *dielectrics;
+  const float4 *emissives;
+  const rt_texture_desc *textures;
+  const uint8_t *texels;
+  uint32_t root_ref; // TLAS root reference (RT_REF_NONE for an empty scene)
+  uint32_t pad;
+};
+
+hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,
+                           uint32_t aabb_mode, unsigned long long *d_counter, hipStream_t stream);
+hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
+                            const rt_render_params &pc, float *d_accum,
+                            unsigned long long *d_counter, hipStream_t stream);
+
+#endif

@@ -1,0 +1,154 @@
+"""GPU parity: librt_hip.so (through its C ABI) against the CPU oracle.
+
+Bar: (t, tri_id, inst_id, u, v) bit-exact on identical ray sets; rendered
+rgba32f images bit-exact (the kernels and the oracle share every rounding, so
+the PSNR >= 40 dB gate of BASELINE.md is met with equality)."""
+import numpy as np
+import pytest
+
+from raytracing_amd import _ffi
+from raytracing_amd import _types as T
+from . import _oracle as O
+from . import _scenes as S
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {"teapot": (S.teapot_scene, S.teapot_camera), "mixed": (S.mixed_scene, S.mixed_camera),
+          "cornell": (S.cornell_builtin, S.cornell_camera)}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.HipContext(0)
+    yield c
+    c.close()
+
+
+def _same_hits(a, b):
+    for f in ("t", "u", "v"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+    assert np.array_equal(a["tri_id"], b["tri_id"]) and np.array_equal(a["inst_id"], b["inst_id"])
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("mode", [T.AABB_DIV, T.AABB_RCP])
+def test_hits_bit_exact_random_rays(ctx, name, mode):
+    sc = SCENES[name][0]().build()
+    ctx.upload_scene(sc)
+    rays = S.random_rays(20000, seed=11, center=(0, 0.5, 0), radius=3.0)
+    want = O.trace_closest(sc, rays, mode)
+    got = ctx.trace_closest(rays, mode)
+    assert (want["tri_id"] != T.INVALID_ID).sum() > 1000
+    _same_hits(got, want)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_hits_bit_exact_camera_and_bounce_rays(ctx, name):
+    make, camf = SCENES[name]
+    sc = make().build()
+    ctx.upload_scene(sc)
+    w, h = 96, 54
+    cam = camf(w, h)
+    pr = O.render_params(w, h, 3, 1, 4)
+    for bounce in (0, 1, 2):
+        rays = O.gen_rays(sc, cam, pr, bounce)
+        if len(rays) == 0:
+            continue
+        _same_hits(ctx.trace_closest(rays), O.trace_closest(sc, rays))
+
+
+def test_ray_edge_cases(ctx):
+    sc = S.mixed_scene().build()
+    ctx.upload_scene(sc)
+    assert len(ctx.trace_closest(np.zeros(0, T.ray_dtype))) == 0  # empty batch
+    rays = S.random_rays(257, seed=5)                             # ragged: not a multiple of the block
+    rays["direction"][0] = (0, 0, 0)                              # degenerate direction: NaN slabs
+    rays["direction"][1] = (0, -1, 0)
+    rays["origin"][2] = (np.inf, 0, 0)
+    rays["direction"][3] = (np.nan, 1, 0)
+    rays["t_max"][4] = 1e-3                                       # range too short to reach anything
+    rays["t_max"][5] = np.inf
+    _same_hits(ctx.trace_closest(rays), O.trace_closest(sc, rays))
+
+
+def test_empty_scene_misses(ctx):
+    r = O.OracleRenderer()
+    r.add_blas(*S.plane_mesh())
+    sc = r.build()  # no instances: tlas_node_count == 0
+    assert sc.tlas_node_count == 0
+    ctx.upload_scene(sc)
+    rays = S.random_rays(100, seed=1)
+    got = ctx.trace_closest(rays)
+    assert (got["tri_id"] == T.INVALID_ID).all() and np.array_equal(got["t"], rays["t_max"])
+
+
+@pytest.mark.parametrize("name,sqrt_spp,depth,rng", [
+    ("cornell", 1, 3, T.RNG_WANG),   # the reference's own launch shape
+    ("cornell", 3, 8, T.RNG_WANG),
+    ("mixed", 2, 8, T.RNG_WANG),
+    ("mixed", 2, 8, T.RNG_PCG),
+    ("teapot", 2, 8, T.RNG_WANG),
+])
+def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng):
+    make, camf = SCENES[name]
+    sc = make().build()
+    ctx.upload_scene(sc)
+    w, h = 100, 52  # not a multiple of the 16x16 tile
+    cam = camf(w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    want = np.zeros((h, w, 4), np.float32)
+    for frame in range(2):  # progressive accumulation across launches
+        p = O.render_params(w, h, frame, sqrt_spp, depth, rng_mode=rng)
+        ctx.render(p)
+        O.render(sc, cam, p, want, nthreads=8)
+    got = ctx.read_accum(w, h)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rays_counted_and_rows(ctx):
+    sc = S.cornell_builtin().build()
+    ctx.upload_scene(sc)
+    w, h = 64, 40
+    cam = S.cornell_camera(w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    ctx.reset_stats()
+    cn = O.Counters()
+    p = O.render_params(w, h, 0, 2, 5)
+    want = O.render(sc, cam, p, counters=cn, nthreads=4)
+    # two row bands == whole frame
+    ctx.render(O.render_params(w, h, 0, 2, 5, row_begin=0, row_end=17))
+    ctx.render(O.render_params(w, h, 0, 2, 5, row_begin=17, row_end=h))
+    got = ctx.read_accum(w, h)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    st = ctx.stats()
+    assert st.rays_traced == cn.rays and st.launches == 2 and st.total_kernel_ms > 0
+
+
+def test_update_instances_moves_object(ctx):
+    r = S.cornell_builtin()
+    sc = r.build()
+    ctx.upload_scene(sc)
+    rays = S.random_rays(5000, seed=3, center=(0, 1, 0), radius=1.5)
+    before = ctx.trace_closest(rays)
+    r.set_blas_instance_transform(6, O.trs((0.0, 0.9, 0.2), (1, 0, 0, 0), (0.5, 0.5, 0.5)))
+    sc2 = r.build()
+    ctx.update_instances(sc2.instances, sc2.tlas_nodes, sc2.tlas_node_count)
+    after = ctx.trace_closest(rays)
+    _same_hits(after, O.trace_closest(sc2, rays))
+    assert not np.array_equal(before["t"], after["t"])
+
+
+def test_bad_input_is_rejected_not_launched(ctx):
+    sc = S.teapot_scene().build()
+    bad = sc.bvh_nodes.copy()
+    bad["local_left_first"][0] = 10 ** 6  # child index outside the BLAS
+    sc_bad = T.SceneArrays(sc.tri_geom, sc.tri_shading, sc.tri_ids, bad, sc.blas, sc.instances,
+                           sc.tlas_nodes, sc.tlas_node_count, sc.lamberts, None, None, None,
+                           sc.textures, sc.texels)
+    with pytest.raises(_ffi.RtError):
+        ctx.upload_scene(sc_bad)
+    with pytest.raises(_ffi.RtError):
+        ctx.trace_closest(S.random_rays(4, 1))  # failed upload leaves no scene
