@@ -323,12 +323,8 @@ int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances, uint32_t
   if (!rt_flatten_tlas(instances, instance_count, tlas_nodes, tlas_node_count, ctx->blas_count,
                        ctx->flat, err))
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
-  ctx->material_counts.texture_count = 0; // textures were validated at upload
-  if (!rt_validate_materials(&ctx->material_counts, instances, instance_count, ctx->flat.inst_live, err)) {
-    ctx->material_counts.texture_count = (uint32_t)ctx->h_textures.size();
+  if (!rt_validate_materials(&ctx->material_counts, instances, instance_count, ctx->flat.inst_live, err))
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
-  }
-  ctx->material_counts.texture_count = (uint32_t)ctx->h_textures.size();
   // kernels in flight still read the old arrays
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return upload_pairs_and_instances(ctx, instances, instance_count);

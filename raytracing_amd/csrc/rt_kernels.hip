@@ -39,7 +39,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 // GLSL.std.450 FMin/FMax wording; NOT v_min_f32/v_max_f32 (those drop NaNs).
 __device__ __forceinline__ float fmin_(float x, float y) { return y < x ? y : x; }
 __device__ __forceinline__ float fmax_(float x, float y) { return x < y ? y : x; }
-__device__ __forceinline__ V3 normalize(V3 v) { return v * (1.0f / __fsqrt_rn(dot(v, v))); }
+__device__ __forceinline__ V3 normalize(V3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 __device__ __forceinline__ V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
 
 // (c0*x + c1*y) + (c2*z + c3*w) — glm operator*(mat4, vec4), xyz rows
@@ -282,7 +282,7 @@ __device__ __forceinline__ V3 rand_unit_vector(Rng &rng) { // Random.slang:34-41
   const float two_pi = 2.0f * 3.14159265359f;
   float z = -1.f + (1.f - -1.f) * rng.next();
   float a = rng.next() * two_pi;
-  float r = __fsqrt_rn(1.f - z * z);
+  float r = sqrtf(1.f - z * z);
   float s, c;
   sincos_det(a, s, c);
   return v3(r * c, r * s, z);
@@ -335,7 +335,7 @@ __device__ __forceinline__ float reflectance(float cosine, float ri) { // Materi
 __device__ __forceinline__ V3 rtiow_refract(V3 uv, V3 n, float eta) { // Material.slang:70-75
   float cos_theta = fmin_(dot(neg(uv), n), 1.0f);
   V3 perp = eta * (uv + cos_theta * n);
-  V3 par = (-__fsqrt_rn(fabsf(1.0f - dot(perp, perp)))) * n;
+  V3 par = (-sqrtf(fabsf(1.0f - dot(perp, perp)))) * n;
   return perp + par;
 }
 
@@ -421,7 +421,7 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
     float ri = front_face ? (1.f / refraction_index) : refraction_index;
     V3 unit = normalize(p.d);
     float cos_theta = fmin_(dot(neg(unit), normal), 1.f);
-    float sin_theta = __fsqrt_rn(fmax_(0.f, 1.f - cos_theta * cos_theta));
+    float sin_theta = sqrtf(fmax_(0.f, 1.f - cos_theta * cos_theta));
     bool cannot_refract = ri * sin_theta > 1.f;
     if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
       out_d = reflect(unit, normal);

@@ -30,6 +30,14 @@ def _same_hits(a, b):
     assert np.array_equal(a["tri_id"], b["tri_id"]) and np.array_equal(a["inst_id"], b["inst_id"])
 
 
+def _same_image(got, want):
+    bad = np.argwhere((got.view(np.uint32) != want.view(np.uint32)).any(-1))
+    if len(bad):
+        y, x = bad[0]
+        raise AssertionError(f"{len(bad)} of {got.shape[0] * got.shape[1]} pixels differ; first at "
+                             f"(x={x}, y={y}): got {got[y, x].tolist()} want {want[y, x].tolist()}")
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 @pytest.mark.parametrize("mode", [T.AABB_DIV, T.AABB_RCP])
 def test_hits_bit_exact_random_rays(ctx, name, mode):
@@ -104,7 +112,7 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng):
         O.render(sc, cam, p, want, nthreads=8)
     got = ctx.read_accum(w, h)
     assert np.isfinite(got).all()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    _same_image(got, want)
 
 
 def test_rays_counted_and_rows(ctx):
@@ -122,7 +130,7 @@ def test_rays_counted_and_rows(ctx):
     ctx.render(O.render_params(w, h, 0, 2, 5, row_begin=0, row_end=17))
     ctx.render(O.render_params(w, h, 0, 2, 5, row_begin=17, row_end=h))
     got = ctx.read_accum(w, h)
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    _same_image(got, want)
     st = ctx.stats()
     assert st.rays_traced == cn.rays and st.launches == 2 and st.total_kernel_ms > 0
 
