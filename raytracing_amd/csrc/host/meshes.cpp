@@ -1,0 +1,349 @@
+// meshes.cpp — see meshes.h.
+#include "meshes.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+#include "hmath.h"
+
+namespace rta {
+
+namespace {
+void push3(std::vector<float> &v, vec3 p) {
+  v.push_back(p.x), v.push_back(p.y), v.push_back(p.z);
+}
+void push2(std::vector<float> &v, float a, float b) { v.push_back(a), v.push_back(b); }
+const float kPiF = 3.14159265358979323846264338327950288f;   // glm::pi<float>()
+const float kTwoPiF = 6.28318530717958647692528676655900576f; // glm::two_pi<float>()
+} // namespace
+
+// src/Renderer.cpp:64-107
+Mesh make_sphere(float radius, uint32_t segments, uint32_t rings) {
+  Mesh m;
+  for (uint32_t y = 0; y <= rings; ++y) {
+    float v = float(y) / rings;
+    float theta = v * kPiF;
+    for (uint32_t x = 0; x <= segments; ++x) {
+      float u = float(x) / segments;
+      float phi = u * kTwoPiF;
+      float sin_theta = sinf(theta), cos_theta = cosf(theta);
+      float sin_phi = sinf(phi), cos_phi = cosf(phi);
+      vec3 normal(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
+      push3(m.positions, vec3(0.f) + radius * normal);
+      push3(m.normals, normal);
+      push2(m.uvs, u, v);
+    }
+  }
+  for (uint32_t y = 0; y < rings; ++y)
+    for (uint32_t x = 0; x < segments; ++x) {
+      uint32_t i0 = y * (segments + 1) + x, i1 = i0 + segments + 1;
+      for (uint32_t i : {i0, i1, i0 + 1, i0 + 1, i1, i1 + 1})
+        m.indices.push_back(i);
+    }
+  return m;
+}
+
+// src/Renderer.cpp:109-145
+Mesh make_plane(float width, float depth, uint32_t x_segments, uint32_t z_segments) {
+  Mesh m;
+  for (uint32_t z = 0; z <= z_segments; ++z) {
+    float vz = float(z) / z_segments;
+    float pos_z = (vz - 0.5f) * depth;
+    for (uint32_t x = 0; x <= x_segments; ++x) {
+      float ux = float(x) / x_segments;
+      float pos_x = (ux - 0.5f) * width;
+      push3(m.positions, vec3(0.f) + vec3(pos_x, 0.f, pos_z));
+      push3(m.normals, vec3(0.f, 1.f, 0.f));
+      push2(m.uvs, ux, vz);
+    }
+  }
+  for (uint32_t z = 0; z < z_segments; ++z)
+    for (uint32_t x = 0; x < x_segments; ++x) {
+      uint32_t i0 = z * (x_segments + 1) + x, i1 = i0 + x_segments + 1;
+      for (uint32_t i : {i0, i1, i0 + 1, i0 + 1, i1, i1 + 1})
+        m.indices.push_back(i);
+    }
+  return m;
+}
+
+// src/Renderer.cpp:147-213
+Mesh make_cube(float width, float height, float depth) {
+  Mesh m;
+  float hx = width * 0.5f, hy = height * 0.5f, hz = depth * 0.5f;
+  auto face = [&](vec3 v0, vec3 v1, vec3 v2, vec3 v3, vec3 n) {
+    uint32_t base = (uint32_t)(m.positions.size() / 3);
+    for (vec3 v : {v0, v1, v2, v3}) {
+      push3(m.positions, vec3(0.f) + v);
+      push3(m.normals, n);
+    }
+    push2(m.uvs, 0, 0), push2(m.uvs, 1, 0), push2(m.uvs, 1, 1), push2(m.uvs, 0, 1);
+    for (uint32_t i : {0u, 1u, 2u, 0u, 2u, 3u})
+      m.indices.push_back(base + i);
+  };
+  face({-hx, -hy, hz}, {hx, -hy, hz}, {hx, hy, hz}, {-hx, hy, hz}, {0, 0, 1});
+  face({hx, -hy, -hz}, {-hx, -hy, -hz}, {-hx, hy, -hz}, {hx, hy, -hz}, {0, 0, -1});
+  face({-hx, -hy, -hz}, {-hx, -hy, hz}, {-hx, hy, hz}, {-hx, hy, -hz}, {-1, 0, 0});
+  face({hx, -hy, hz}, {hx, -hy, -hz}, {hx, hy, -hz}, {hx, hy, hz}, {1, 0, 0});
+  face({-hx, hy, hz}, {hx, hy, hz}, {hx, hy, -hz}, {-hx, hy, -hz}, {0, 1, 0});
+  face({-hx, -hy, -hz}, {hx, -hy, -hz}, {hx, -hy, hz}, {-hx, -hy, hz}, {0, -1, 0});
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// Dragon-class stand-in.
+// ---------------------------------------------------------------------------
+namespace {
+struct D3 {
+  double x, y, z;
+};
+D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+D3 dcross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+D3 dnorm(D3 a) {
+  double l = sqrt(ddot(a, a));
+  return l > 0 ? a * (1.0 / l) : D3{0, 1, 0};
+}
+D3 knot(double t) { // (2,3) torus knot, fits a ~2.6 x 1.3 x 2.6 box
+  double r = 0.8 + 0.35 * cos(3 * t);
+  return {r * cos(2 * t), 0.45 * sin(3 * t) + 0.55, r * sin(2 * t)};
+}
+// integer lattice hash -> [0,1)
+double lattice(uint32_t i, uint32_t j, uint32_t seed) {
+  uint32_t h = i * 0x9E3779B1u ^ (j * 0x85EBCA77u + seed * 0xC2B2AE3Du);
+  h ^= h >> 15, h *= 0x2C1B3C6Du, h ^= h >> 12, h *= 0x297A2D39u, h ^= h >> 15;
+  return (double)h / 4294967296.0;
+}
+// periodic value noise on a cu x cv lattice
+double vnoise(double u, double v, uint32_t cu, uint32_t cv, uint32_t seed) {
+  double fu = u * cu, fv = v * cv;
+  uint32_t iu = (uint32_t)floor(fu), iv = (uint32_t)floor(fv);
+  double a = fu - iu, b = fv - iv;
+  a = a * a * (3 - 2 * a), b = b * b * (3 - 2 * b);
+  auto L = [&](uint32_t x, uint32_t y) { return lattice(x % cu, y % cv, seed); };
+  double n0 = L(iu, iv) * (1 - a) + L(iu + 1, iv) * a;
+  double n1 = L(iu, iv + 1) * (1 - a) + L(iu + 1, iv + 1) * a;
+  return n0 * (1 - b) + n1 * b;
+}
+} // namespace
+
+Mesh make_dragon(uint32_t u_seg, uint32_t v_seg, uint32_t seed) {
+  Mesh m;
+  if (u_seg < 3 || v_seg < 3)
+    return m;
+  const double two_pi = 6.283185307179586476925286766559;
+  const size_t nv = (size_t)u_seg * v_seg;
+  std::vector<D3> P(nv);
+  for (uint32_t i = 0; i < u_seg; ++i) {
+    double u = (double)i / u_seg, t = u * two_pi;
+    D3 c = knot(t);
+    D3 tan = dnorm(knot(t + 1e-4) - knot(t - 1e-4));
+    D3 up = dnorm(dcross(tan, dcross(D3{0, 1, 0}, tan))); // up made orthogonal to the tangent
+    D3 side = dcross(tan, up);
+    // body radius: thick "torso", thin "neck/tail", periodic over the loop
+    double body = 0.16 + 0.06 * sin(t * 2 + 0.7) + 0.03 * sin(t * 5 + 1.9);
+    for (uint32_t j = 0; j < v_seg; ++j) {
+      double v = (double)j / v_seg, a = v * two_pi;
+      double ridge = pow(fmax(0.0, cos(a)), 24.0) * (0.55 + 0.45 * sin(t * 40)); // dorsal crest
+      double scales = 0.5 + 0.5 * sin(t * 180 + (j & 1) * 3.14159) * sin(a * 24);   // scale rows
+      double r = body * (1.0 + 0.55 * ridge + 0.06 * scales + 0.25 * (vnoise(u, v, 48, 12, seed) - 0.5) +
+                         0.10 * (vnoise(u, v, 400, 64, seed + 1) - 0.5) +
+                         0.04 * (vnoise(u, v, 1700, 256, seed + 2) - 0.5));
+      // spikes: sparse lattice cells pushed outwards
+      if (lattice(i / 6, j / 6, seed + 3) > 0.985)
+        r *= 1.0 + 0.8 * sin(3.14159 * ((i % 6) + 0.5) / 6.0) * sin(3.14159 * ((j % 6) + 0.5) / 6.0);
+      P[(size_t)i * v_seg + j] = c + (up * cos(a) + side * sin(a)) * r;
+    }
+  }
+  // area-weighted vertex normals
+  std::vector<D3> N(nv, D3{0, 0, 0});
+  m.indices.reserve(nv * 6);
+  for (uint32_t i = 0; i < u_seg; ++i)
+    for (uint32_t j = 0; j < v_seg; ++j) {
+      uint32_t i1 = (i + 1) % u_seg, j1 = (j + 1) % v_seg;
+      uint32_t a = i * v_seg + j, b = i1 * v_seg + j, c = i1 * v_seg + j1, d = i * v_seg + j1;
+      for (auto tri : {std::tuple<uint32_t, uint32_t, uint32_t>{a, b, c}, {a, c, d}}) {
+        uint32_t p = std::get<0>(tri), q = std::get<1>(tri), r = std::get<2>(tri);
+        D3 fn = dcross(P[q] - P[p], P[r] - P[p]);
+        N[p] = N[p] + fn, N[q] = N[q] + fn, N[r] = N[r] + fn;
+        m.indices.push_back(p), m.indices.push_back(q), m.indices.push_back(r);
+      }
+    }
+  m.positions.reserve(nv * 3), m.normals.reserve(nv * 3), m.uvs.reserve(nv * 2);
+  for (size_t k = 0; k < nv; ++k) {
+    D3 n = dnorm(N[k]);
+    m.positions.push_back((float)P[k].x), m.positions.push_back((float)P[k].y),
+        m.positions.push_back((float)P[k].z);
+    m.normals.push_back((float)n.x), m.normals.push_back((float)n.y), m.normals.push_back((float)n.z);
+    m.uvs.push_back((float)((double)(k / v_seg) / u_seg)), m.uvs.push_back((float)((double)(k % v_seg) / v_seg));
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// OBJ / MTL
+// ---------------------------------------------------------------------------
+namespace {
+std::string dirname_of(const std::string &p) {
+  size_t s = p.find_last_of("/\\");
+  return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+void load_mtl(const std::string &path, std::vector<ObjMaterial> &mats) {
+  std::ifstream in(path);
+  if (!in)
+    return; // tinyobj only warns when the .mtl is missing
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string key;
+    if (!(ss >> key) || key[0] == '#')
+      continue;
+    if (key == "newmtl") {
+      ObjMaterial m;
+      ss >> m.name;
+      m.kd[0] = m.kd[1] = m.kd[2] = 0.6f; // tinyobj's default diffuse when Kd is absent
+      mats.push_back(m);
+    } else if (!mats.empty() && key == "Kd") {
+      ss >> mats.back().kd[0] >> mats.back().kd[1] >> mats.back().kd[2];
+      mats.back().has_kd = true;
+    } else if (!mats.empty() && key == "map_Kd") {
+      ss >> mats.back().map_kd;
+    }
+  }
+}
+
+struct Corner {
+  int v, t, n;
+};
+struct VKey {
+  float f[8];
+  bool operator<(const VKey &o) const { return memcmp(f, o.f, sizeof f) < 0; }
+};
+} // namespace
+
+bool load_obj(const std::string &path, ObjModel &out, std::string &err) {
+  std::ifstream in(path);
+  if (!in) {
+    err = "cannot open " + path;
+    return false;
+  }
+  out = ObjModel();
+  std::vector<float> vs, vns, vts;
+  std::map<int, size_t> group_of_material; // material id -> group index
+  std::vector<std::map<VKey, uint32_t>> weld;
+  int current_material = -1;
+  std::string line;
+  size_t line_no = 0;
+  while (std::getline(in, line)) {
+    ++line_no;
+    std::istringstream ss(line);
+    std::string key;
+    if (!(ss >> key) || key[0] == '#')
+      continue;
+    if (key == "v") {
+      float x, y, z;
+      if (!(ss >> x >> y >> z)) {
+        err = path + ":" + std::to_string(line_no) + ": bad vertex";
+        return false;
+      }
+      vs.push_back(x), vs.push_back(y), vs.push_back(z);
+    } else if (key == "vn") {
+      float x = 0, y = 0, z = 0;
+      ss >> x >> y >> z;
+      vns.push_back(x), vns.push_back(y), vns.push_back(z);
+    } else if (key == "vt") {
+      float u = 0, v = 0;
+      ss >> u >> v;
+      vts.push_back(u), vts.push_back(v);
+    } else if (key == "mtllib") {
+      std::string name;
+      ss >> name;
+      load_mtl(dirname_of(path) + "/" + name, out.materials);
+    } else if (key == "usemtl") {
+      std::string name;
+      ss >> name;
+      current_material = -1;
+      for (size_t i = 0; i < out.materials.size(); ++i)
+        if (out.materials[i].name == name)
+          current_material = (int)i;
+    } else if (key == "f") {
+      std::vector<Corner> corners;
+      std::string tok;
+      while (ss >> tok) {
+        Corner c{0, 0, 0};
+        int *slot[3] = {&c.v, &c.t, &c.n};
+        size_t pos = 0;
+        for (int k = 0; k < 3 && pos <= tok.size(); ++k) {
+          size_t slash = tok.find('/', pos);
+          std::string part = tok.substr(pos, slash == std::string::npos ? std::string::npos : slash - pos);
+          if (!part.empty())
+            *slot[k] = atoi(part.c_str());
+          if (slash == std::string::npos)
+            break;
+          pos = slash + 1;
+        }
+        int nv = (int)(vs.size() / 3), nt = (int)(vts.size() / 2), nn = (int)(vns.size() / 3);
+        c.v = c.v > 0 ? c.v - 1 : (c.v < 0 ? nv + c.v : -1);
+        c.t = c.t > 0 ? c.t - 1 : (c.t < 0 ? nt + c.t : -1);
+        c.n = c.n > 0 ? c.n - 1 : (c.n < 0 ? nn + c.n : -1);
+        if (c.v < 0 || c.v >= nv || c.t >= nt || c.n >= nn) {
+          err = path + ":" + std::to_string(line_no) + ": face index out of range";
+          return false;
+        }
+        corners.push_back(c);
+      }
+      if (corners.size() < 3)
+        continue;
+      auto it = group_of_material.find(current_material);
+      if (it == group_of_material.end()) {
+        it = group_of_material.emplace(current_material, out.groups.size()).first;
+        out.groups.emplace_back();
+        out.group_material.push_back(current_material);
+        weld.emplace_back();
+      }
+      Mesh &g = out.groups[it->second];
+      std::map<VKey, uint32_t> &w = weld[it->second];
+      for (size_t k = 1; k + 1 < corners.size(); ++k) { // fan
+        const Corner tri[3] = {corners[0], corners[k], corners[k + 1]};
+        vec3 p[3];
+        for (int q = 0; q < 3; ++q)
+          p[q] = vec3(&vs[3 * (size_t)tri[q].v]);
+        vec3 fn = cross(p[1] - p[0], p[2] - p[0]);
+        float fl = length(fn);
+        fn = fl > 0.f ? fn / fl : vec3(0.f, 1.f, 0.f);
+        for (int q = 0; q < 3; ++q) {
+          vec3 n = tri[q].n >= 0 ? vec3(&vns[3 * (size_t)tri[q].n]) : fn;
+          float u = 0.f, v = 0.f;
+          if (tri[q].t >= 0) {
+            u = vts[2 * (size_t)tri[q].t];
+            v = 1.0f - vts[2 * (size_t)tri[q].t + 1]; // Scene.cpp:91-93
+          }
+          VKey key{{p[q].x, p[q].y, p[q].z, n.x, n.y, n.z, u, v}};
+          auto found = w.find(key);
+          if (found == w.end()) {
+            found = w.emplace(key, (uint32_t)(g.positions.size() / 3)).first;
+            push3(g.positions, p[q]);
+            push3(g.normals, n);
+            push2(g.uvs, u, v);
+          }
+          g.indices.push_back(found->second);
+        }
+      }
+    }
+  }
+  if (out.groups.empty()) {
+    err = path + ": no faces";
+    return false;
+  }
+  return true;
+}
+
+} // namespace rta
