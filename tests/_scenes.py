@@ -111,7 +111,7 @@ def load_obj(path):
                     for c, pp in zip(tri, P):
                         pos.append(pp)
                         nrm.append(np.array(vns[c[2]], F) if c[2] is not None else fn)
-                        uv.append((vts[c[1]][0], 1.0 - vts[c[1]][1]) if c[1] is not None else (0.0, 0.0))
+                        uv.append((F(vts[c[1]][0]), F(1.0) - F(vts[c[1]][1])) if c[1] is not None else (0.0, 0.0))
     n = len(pos)
     return np.array(pos, F), np.array(nrm, F), np.array(uv, F), np.arange(n, dtype=np.uint32)
 
