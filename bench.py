@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)

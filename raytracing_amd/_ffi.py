@@ -47,6 +47,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
                           "(make -C raytracing_amd/csrc); there is no fallback path")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 (same
+    # SONAME as /opt/rocm's).  Whichever is mapped first serves both, and a
+    # process that maps ROCm's first and then initialises torch's device state
+    # ends up with a runtime that reports no device to this library.  Import
+    # torch first (when present) so both always share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
     L.rt_create.argtypes = [C.c_int, C.POINTER(vp)]

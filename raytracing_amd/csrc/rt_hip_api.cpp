@@ -74,6 +74,7 @@ struct rt_ctx {
   DevBuf<rt_texture_desc> textures;
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
+  DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -90,7 +91,7 @@ struct rt_ctx {
   bool accum_bound = false;
   rt_camera_uniforms camera{};
   bool have_camera = false;
-  uint32_t variant = 0;
+  uint32_t variant = 1; // persistent path-regeneration kernel
   // timing
   std::vector<EventPair> pending, free_events;
   double total_ms = 0.0, last_ms = 0.0;
@@ -210,6 +211,8 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
   if (e == hipSuccess)
     e = ctx->counter.reserve(1);
   if (e == hipSuccess)
+    e = ctx->queue.reserve(64);
+  if (e == hipSuccess)
     e = hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) {
     delete ctx;
@@ -245,6 +248,7 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->textures.release();
   ctx->texels.release();
   ctx->counter.release();
+  ctx->queue.release();
   ctx->accum_own.release();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -408,7 +412,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (rc != RT_OK)
     return rc;
   HIP_TRY(rt_launch_render(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                           ctx->stream));
+                           ctx->queue.ptr, ctx->stream));
   return end_timed(ctx, ev);
 }
 

@@ -560,6 +560,102 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
+// k_render_v1: persistent wave64s with path regeneration.  Per pixel the
+// arithmetic and the RNG draw order are those of k_render_v0 (so the image is
+// the same bit for bit); what changes is the schedule:
+//   * a lane whose path ended (sky, light, depth) starts its pixel's next
+//     sample at once instead of idling until the longest path of the wave ends;
+//   * a lane whose pixel is finished pulls the next pixel from a global queue
+//     (one wave-aggregated atomic per refill), in 8x8-tile order so that the
+//     lanes of a wave keep working on neighbouring pixels;
+//   * the grid is sized to the chip (resident blocks only), every lane runs
+//     until the queue is empty, every wave leaves when its 64 lanes are done.
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+    k_render_v1(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
+                float4 *__restrict__ accum, unsigned long long *ray_counter,
+                uint32_t *__restrict__ queue) {
+  __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
+  Stack st;
+  st.lds = lds_stack + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
+  const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+
+  bool alive = true, have_pixel = false, have_path = false;
+  uint32_t x = 0, y = 0, sample = 0, depth = 0, traced = 0;
+  Rng rng = make_rng(pc, 0, 0);
+  V3 radiance = v3(0.f, 0.f, 0.f);
+  Path p;
+  p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
+
+  while (true) {
+    // ---- refill: pixels for lanes that have none ----
+    while (true) {
+      const bool need = alive && !have_pixel;
+      const unsigned long long mask = __ballot(need);
+      if (mask == 0ull)
+        break;
+      const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(queue, (uint32_t)__popcll(mask));
+      base = __shfl(base, (int)leader, 64);
+      if (need) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (slot >= total_slots) {
+          alive = false;
+        } else {
+          const uint32_t tile = slot >> 6, in = slot & 63u;
+          x = (tile % tiles_x) * 8u + (in & 7u);
+          y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+          if (x < pc.image_width && y < pc.row_end) { // else: edge padding, fetch again
+            have_pixel = true;
+            have_path = false;
+            sample = 0;
+            rng = make_rng(pc, x, y);
+            radiance = v3(0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+    if (__ballot(alive) == 0ull)
+      break;
+    // ---- regenerate: next camera ray of the lane's pixel ----
+    if (have_pixel && !have_path) {
+      rng.sample = pc.frame_index * spp + sample;
+      rng.set_slot(0);
+      camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+      depth = 0;
+      have_path = true;
+    }
+    // ---- one bounce for every lane that has a path ----
+    bool path_ends = have_path;
+    if (have_path && depth < pc.max_depth) {
+      rng.set_slot(depth + 1);
+      Hit hit;
+      const bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
+      ++traced;
+      const bool scattered = shade(sc, any, hit, rng, p);
+      ++depth;
+      path_ends = !scattered || depth >= pc.max_depth;
+    }
+    if (have_path && path_ends) {
+      radiance = radiance + p.sample_radiance; // RayTracing.slang:170
+      have_path = false;
+      if (++sample == spp) {
+        accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
+        have_pixel = false;
+      }
+    }
+  }
+  count_rays(ray_counter, traced);
+}
+
+// ---------------------------------------------------------------------------
 // Launchers (host).  Shapes are validated by the caller (rt_hip_api.cpp).
 // ---------------------------------------------------------------------------
 hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,
@@ -576,13 +672,39 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
 
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
-                            unsigned long long *d_counter, hipStream_t stream) {
-  (void)variant;
+                            unsigned long long *d_counter, uint32_t *d_queue, hipStream_t stream) {
   uint32_t rows = pc.row_end - pc.row_begin;
-  uint32_t tiles = ((pc.image_width + 15u) >> 4) * ((rows + 15u) >> 4);
-  if (tiles == 0)
+  if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(k_render_v0, dim3(tiles), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
-                     reinterpret_cast<float4 *>(d_accum), d_counter);
+  if (variant == 0) {
+    uint32_t tiles = ((pc.image_width + 15u) >> 4) * ((rows + 15u) >> 4);
+    hipLaunchKernelGGL(k_render_v0, dim3(tiles), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
+                       reinterpret_cast<float4 *>(d_accum), d_counter);
+    return hipGetLastError();
+  }
+  // persistent grid: only as many blocks as the chip holds at once
+  static int resident_blocks = 0;
+  if (resident_blocks == 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess)
+      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_v1, RT_BLOCK, 0);
+    if (e != hipSuccess)
+      return e;
+    if (per_cu < 1)
+      per_cu = 1;
+    resident_blocks = cus * per_cu;
+  }
+  uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
+  uint32_t blocks = (uint32_t)((slots + RT_BLOCK - 1) / RT_BLOCK);
+  if (blocks > (uint32_t)resident_blocks)
+    blocks = (uint32_t)resident_blocks;
+  hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
+                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
   return hipGetLastError();
 }

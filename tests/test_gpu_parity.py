@@ -90,6 +90,7 @@ def test_empty_scene_misses(ctx):
     assert (got["tri_id"] == T.INVALID_ID).all() and np.array_equal(got["t"], rays["t_max"])
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name,sqrt_spp,depth,rng", [
     ("cornell", 1, 3, T.RNG_WANG),   # the reference's own launch shape
     ("cornell", 3, 8, T.RNG_WANG),
@@ -97,10 +98,11 @@ def test_empty_scene_misses(ctx):
     ("mixed", 2, 8, T.RNG_PCG),
     ("teapot", 2, 8, T.RNG_WANG),
 ])
-def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng):
+def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng, variant):
     make, camf = SCENES[name]
     sc = make().build()
     ctx.upload_scene(sc)
+    ctx.set_kernel_variant(variant)
     w, h = 100, 52  # not a multiple of the 16x16 tile
     cam = camf(w, h)
     ctx.set_camera(cam)
@@ -111,13 +113,16 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng):
         ctx.render(p)
         O.render(sc, cam, p, want, nthreads=8)
     got = ctx.read_accum(w, h)
+    ctx.set_kernel_variant(0)
     assert np.isfinite(got).all()
     _same_image(got, want)
 
 
-def test_rays_counted_and_rows(ctx):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_rays_counted_and_rows(ctx, variant):
     sc = S.cornell_builtin().build()
     ctx.upload_scene(sc)
+    ctx.set_kernel_variant(variant)
     w, h = 64, 40
     cam = S.cornell_camera(w, h)
     ctx.set_camera(cam)
@@ -132,6 +137,7 @@ def test_rays_counted_and_rows(ctx):
     got = ctx.read_accum(w, h)
     _same_image(got, want)
     st = ctx.stats()
+    ctx.set_kernel_variant(0)
     assert st.rays_traced == cn.rays and st.launches == 2 and st.total_kernel_ms > 0
 
 
