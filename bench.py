@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -212,7 +212,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "kernel": "k_render_v%d" % args.variant, "kernel_ms": kernel_ms,
+                    "kernel": "k_render_v%d" % (args.variant & 0xFF), "kernel_ms": kernel_ms,
                     "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch}
 
     out = {

@@ -91,7 +91,8 @@ struct rt_ctx {
   bool accum_bound = false;
   rt_camera_uniforms camera{};
   bool have_camera = false;
-  uint32_t variant = 1; // persistent path-regeneration kernel
+  uint32_t variant = 2; // persistent, regenerating, resumable-traversal kernel
+  uint32_t regen_idle = 16; // v2: regenerate once this many lanes of a wave are idle
   // timing
   std::vector<EventPair> pending, free_events;
   double total_ms = 0.0, last_ms = 0.0;
@@ -412,7 +413,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (rc != RT_OK)
     return rc;
   HIP_TRY(rt_launch_render(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                           ctx->queue.ptr, ctx->stream));
+                           ctx->queue.ptr, ctx->regen_idle, ctx->stream));
   return end_timed(ctx, ev);
 }
 
@@ -527,9 +528,11 @@ int rt_reset_stats(rt_ctx *ctx) {
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || variant > 1)
+  if (!ctx || (variant & 0xFFu) > 2)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
-  ctx->variant = variant;
+  ctx->variant = variant & 0xFFu;
+  if (variant >> 8) // tuning knob for experiments: bits 8.. = regen_idle
+    ctx->regen_idle = variant >> 8;
   return RT_OK;
 }
 

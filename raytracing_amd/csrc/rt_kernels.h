@@ -30,6 +30,7 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
                            uint32_t aabb_mode, unsigned long long *d_counter, hipStream_t stream);
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
-                            unsigned long long *d_counter, uint32_t *d_queue, hipStream_t stream);
+                            unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
+                            hipStream_t stream);
 
 #endif

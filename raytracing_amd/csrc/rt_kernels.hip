@@ -656,6 +656,220 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
+// k_render_v2: persistent wave64s, path regeneration AND resumable traversal.
+// Profiling k_render_v1 (profiles/r01_v1_persistent) showed 19 % VALU lane
+// utilisation: a wave waits for its longest ray while sky rays finish after a
+// handful of nodes.  Here the traversal itself is a per-lane state machine
+// (reference, stack pointer, object-space ray, closest hit live in registers /
+// LDS between steps): the wave runs traversal steps until `regen_idle` lanes
+// have finished their ray (or none is traversing any more); then it shades
+// those lanes, regenerates their next ray (next bounce, next sample or
+// next pixel from the queue) and resumes — the unfinished lanes simply carry
+// on.  Per pixel the sequence of arithmetic and RNG draws is unchanged.
+// ---------------------------------------------------------------------------
+enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
+
+template <int MODE>
+__global__ void __launch_bounds__(RT_BLOCK)
+    k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
+                float4 *__restrict__ accum, unsigned long long *ray_counter,
+                uint32_t *__restrict__ queue, uint32_t regen_idle) {
+  __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
+  Stack st;
+  st.lds = lds_stack + threadIdx.x;
+  st.sp = 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
+  const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+
+  uint32_t state = ST_FETCH;
+  uint32_t x = 0, y = 0, sample = 0, depth = 0, traced = 0;
+  Rng rng = make_rng(pc, 0, 0);
+  V3 radiance = v3(0.f, 0.f, 0.f);
+  Path p;
+  p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
+  // traversal state of the lane's current ray
+  uint32_t ref = RT_REF_NONE, cur_inst = 0;
+  V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
+  float closest = 0.f;
+  bool any = false;
+  Hit hit;
+  hit.t = 0.f, hit.u = hit.v = 0.f, hit.tri = hit.inst = 0;
+
+  while (true) {
+    // ---- (1) lanes whose ray is finished: shade, then continue / end the path ----
+    if (state == ST_SHADE) {
+      const bool scattered = shade(sc, any, hit, rng, p);
+      ++depth;
+      if (scattered && depth < pc.max_depth) {
+        state = ST_NEWPATH + 100u; // marker: start the next bounce below
+      } else {
+        radiance = radiance + p.sample_radiance; // RayTracing.slang:170
+        if (++sample == spp) {
+          accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
+          state = ST_FETCH;
+        } else {
+          state = ST_NEWPATH;
+        }
+      }
+    }
+    // ---- (2) lanes without a pixel: pull from the queue (wave-uniform loop) ----
+    while (true) {
+      const bool need = state == ST_FETCH;
+      const unsigned long long mask = __ballot(need);
+      if (mask == 0ull)
+        break;
+      const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(queue, (uint32_t)__popcll(mask));
+      base = __shfl(base, (int)leader, 64);
+      if (need) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (slot >= total_slots) {
+          state = ST_DONE;
+        } else {
+          const uint32_t tile = slot >> 6, in = slot & 63u;
+          x = (tile % tiles_x) * 8u + (in & 7u);
+          y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+          if (x < pc.image_width && y < pc.row_end) { // else edge padding: fetch again
+            state = ST_NEWPATH;
+            sample = 0;
+            rng = make_rng(pc, x, y);
+            radiance = v3(0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+    if (__ballot(state != ST_DONE) == 0ull)
+      break;
+    // ---- (3) new camera ray / next bounce: arm the traversal ----
+    if (state == ST_NEWPATH) {
+      rng.sample = pc.frame_index * spp + sample;
+      rng.set_slot(0);
+      camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+      depth = 0;
+      if (pc.max_depth == 0) { // degenerate: the sample contributes nothing (RayTracing.slang:92)
+        if (++sample == spp) {
+          accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
+          state = ST_FETCH;
+        }
+      } else {
+        state = ST_NEWPATH + 100u;
+      }
+    }
+    if (state == ST_NEWPATH + 100u) {
+      rng.set_slot(depth + 1);
+      ++traced;
+      ref = sc.root_ref;
+      co = p.o, cd = p.d;
+      if (MODE == RT_AABB_RCP)
+        cinv = inv_direction(p.d);
+      closest = 1000.f; // RayTracing.slang:93-95
+      any = false;
+      cur_inst = 0;
+      st.sp = 0;
+      state = ref == RT_REF_NONE ? ST_SHADE : ST_TRAVERSE;
+    }
+    // ---- (4) traversal steps while enough lanes are traversing ----
+    do {
+      if (state == ST_TRAVERSE) {
+        bool do_pop = false;
+        if (!(ref & RT_REF_LEAF)) {
+          const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+          float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+          float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+          uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
+          if (dist1 > dist2) {
+            float tf = dist1;
+            dist1 = dist2;
+            dist2 = tf;
+            uint32_t tc = c1;
+            c1 = c2;
+            c2 = tc;
+          }
+          if (dist1 == kMiss) {
+            do_pop = true;
+          } else {
+            if (dist2 != kMiss)
+              st.push(c2);
+            ref = c1;
+          }
+        } else if (ref & RT_REF_INST) {
+          cur_inst = ref & 0x3FFFFFFFu;
+          const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+          float4 a = q[0], b = q[1], c = q[2], e = q[3];
+          V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
+             c3 = v3(e.x, e.y, e.z);
+          co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
+          cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+          if (MODE == RT_AABB_RCP)
+            cinv = inv_direction(cd);
+          st.push(RT_REF_SENTINEL);
+          ref = __float_as_uint(a.w);
+        } else {
+          uint32_t k = ref & 0x7FFFFFFFu;
+          uint32_t last;
+          do {
+            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
+            float4 t0 = q[0], t1 = q[1], t2 = q[2];
+            last = __float_as_uint(t1.w);
+            ++k;
+            V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
+               edge_2 = v3(t2.x, t2.y, t2.z);
+            V3 h = cross(cd, edge_2);
+            float a = dot(edge_1, h);
+            if (a > -kEpsilon && a < kEpsilon)
+              continue;
+            float f = 1.f / a;
+            V3 s = co - v0;
+            float u = f * dot(s, h);
+            if (u < 0 || u > 1)
+              continue;
+            V3 qq = cross(s, edge_1);
+            float v = f * dot(cd, qq);
+            if (v < 0 || u + v > 1)
+              continue;
+            float t = f * dot(edge_2, qq);
+            if (t < kEpsilon || !(0.0001f <= t && t <= closest))
+              continue;
+            closest = t;
+            any = true;
+            hit.t = t;
+            hit.u = u;
+            hit.v = v;
+            hit.tri = __float_as_uint(t0.w);
+            hit.inst = cur_inst;
+          } while (!last);
+          do_pop = true;
+        }
+        if (do_pop) {
+          while (true) {
+            if (st.sp == 0) {
+              state = ST_SHADE;
+              break;
+            }
+            ref = st.pop();
+            if (ref != RT_REF_SENTINEL)
+              break;
+            co = p.o;
+            cd = p.d;
+            if (MODE == RT_AABB_RCP)
+              cinv = inv_direction(p.d);
+          }
+        }
+      }
+    } while (__ballot(state == ST_TRAVERSE) != 0ull &&
+             (uint32_t)__popcll(__ballot(state == ST_SHADE)) < regen_idle);
+  }
+  count_rays(ray_counter, traced);
+}
+
+// ---------------------------------------------------------------------------
 // Launchers (host).  Shapes are validated by the caller (rt_hip_api.cpp).
 // ---------------------------------------------------------------------------
 hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,
@@ -672,7 +886,8 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
 
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
-                            unsigned long long *d_counter, uint32_t *d_queue, hipStream_t stream) {
+                            unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
+                            hipStream_t stream) {
   uint32_t rows = pc.row_end - pc.row_begin;
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
@@ -704,7 +919,15 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
-  hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
-                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
+  if (variant == 1) {
+    hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
+                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
+  } else if (pc.aabb_mode == RT_AABB_RCP) {
+    hipLaunchKernelGGL(k_render_v2<RT_AABB_RCP>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
+                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+  } else {
+    hipLaunchKernelGGL(k_render_v2<RT_AABB_DIV>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
+                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+  }
   return hipGetLastError();
 }
