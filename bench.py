@@ -87,6 +87,7 @@ def main():
     import torch.distributed as dist
     from raytracing_amd import _ffi, _types as T
     from raytracing_amd import renderer as R
+    from raytracing_amd import sharding
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -105,8 +106,9 @@ def main():
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
     r.set_option(R.OPT_MAX_DEPTH, args.depth)
     r.set_option(R.OPT_AABB_MODE, T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV)
-    r.set_option(R.OPT_FRAME_STRIDE, world)
-    r.set_option(R.OPT_FRAME_OFFSET, rank)
+    shard = sharding.frame_shard(rank, world)
+    r.set_option(R.OPT_FRAME_STRIDE, shard["frame_stride"])
+    r.set_option(R.OPT_FRAME_OFFSET, shard["frame_offset"])
     r.set_option(R.OPT_KERNEL_VARIANT, args.variant)
     ctx = C.c_void_p(r.hip_context_handle())
     L = _ffi.lib()
@@ -121,8 +123,7 @@ def main():
         r.render(cam)          # one launch: args.spp samples for every pixel
         if world > 1:
             r.wait()           # kernel runs on the library's stream
-            reduced.copy_(accum)
-            dist.reduce(reduced, dst=0, op=dist.ReduceOp.SUM)  # rank 0: sum of N running means
+            sharding.combine(accum, out=reduced, dst=0)  # rank 0: (1/N) * sum of the N running means
 
     def fence():
         r.wait()

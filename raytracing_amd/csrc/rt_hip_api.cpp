@@ -530,9 +530,10 @@ int rt_reset_stats(rt_ctx *ctx) {
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
   if (!ctx || (variant & 0xFFu) > 2)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
-  ctx->variant = variant & 0xFFu;
-  if (variant >> 8) // tuning knob for experiments: bits 8.. = regen_idle
-    ctx->regen_idle = variant >> 8;
+  // bits 0-7 kernel, 8-15 regen_idle (0 = keep), 16-19 waves/SIMD build of v2 (experiment knobs)
+  ctx->variant = variant & 0xFF00FFu;
+  if ((variant >> 8) & 0xFFu)
+    ctx->regen_idle = (variant >> 8) & 0xFFu;
   return RT_OK;
 }
 

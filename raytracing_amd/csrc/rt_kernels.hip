@@ -669,8 +669,8 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 // ---------------------------------------------------------------------------
 enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
-template <int MODE>
-__global__ void __launch_bounds__(RT_BLOCK)
+template <int MODE, int MINW>
+__global__ void __launch_bounds__(RT_BLOCK, MINW)
     k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
                 uint32_t *__restrict__ queue, uint32_t regen_idle) {
@@ -891,43 +891,51 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   uint32_t rows = pc.row_end - pc.row_begin;
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  if (variant == 0) {
+  if ((variant & 0xFFu) == 0) {
     uint32_t tiles = ((pc.image_width + 15u) >> 4) * ((rows + 15u) >> 4);
     hipLaunchKernelGGL(k_render_v0, dim3(tiles), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter);
     return hipGetLastError();
   }
   // persistent grid: only as many blocks as the chip holds at once
-  static int resident_blocks = 0;
-  if (resident_blocks == 0) {
-    int dev = 0, cus = 0, per_cu = 0;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess)
       e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_v1, RT_BLOCK, 0);
     if (e != hipSuccess)
       return e;
-    if (per_cu < 1)
-      per_cu = 1;
-    resident_blocks = cus * per_cu;
   }
-  uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
-  uint32_t blocks = (uint32_t)((slots + RT_BLOCK - 1) / RT_BLOCK);
-  if (blocks > (uint32_t)resident_blocks)
-    blocks = (uint32_t)resident_blocks;
+  const uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
+  auto blocks_for = [&](uint32_t waves_per_simd) { // 4 SIMDs per CU, RT_BLOCK/64 waves per block
+    uint64_t resident = (uint64_t)cus * (waves_per_simd * 4u / (RT_BLOCK / 64u));
+    uint64_t need = (slots + RT_BLOCK - 1) / RT_BLOCK;
+    return (uint32_t)(need < resident ? need : resident);
+  };
+  uint32_t blocks = blocks_for(4);
   hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
-  if (variant == 1) {
+  if ((variant & 0xFFu) == 1) {
     hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
-  } else if (pc.aabb_mode == RT_AABB_RCP) {
-    hipLaunchKernelGGL(k_render_v2<RT_AABB_RCP>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
-                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
   } else {
-    hipLaunchKernelGGL(k_render_v2<RT_AABB_DIV>, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
-                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+#define RT_V2(MODE, W)                                                                              \
+  hipLaunchKernelGGL((k_render_v2<MODE, W>), dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,     \
+                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle)
+    const uint32_t w = variant >> 16; // experiment knob: min waves per SIMD the kernel is compiled for
+    blocks = blocks_for(w == 0 ? 4 : w);
+    if (pc.aabb_mode == RT_AABB_RCP) {
+      if (w == 5) RT_V2(RT_AABB_RCP, 5);
+      else if (w == 6) RT_V2(RT_AABB_RCP, 6);
+      else RT_V2(RT_AABB_RCP, 4);
+    } else {
+      if (w == 5) RT_V2(RT_AABB_DIV, 5);
+      else if (w == 6) RT_V2(RT_AABB_DIV, 6);
+      else RT_V2(RT_AABB_DIV, 4);
+    }
+#undef RT_V2
   }
   return hipGetLastError();
 }

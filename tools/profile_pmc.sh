@@ -19,4 +19,7 @@ pass sq2 SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INST_LEVEL_VM
 pass tcc1 FETCH_SIZE TCC_HIT_sum || exit 1
 pass tcc2 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum || exit 1
 pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum || exit 1
+pass ta1 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum || exit 1
+pass tcp2 TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum || exit 1
+pass tcp3 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum || exit 1
 echo done
