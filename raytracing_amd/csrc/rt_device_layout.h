@@ -53,5 +53,6 @@ struct alignas(64) rt_dev_inst { // 64 B: what a TLAS leaf visit needs
 #define RT_LDS_STACK 24   // stack entries per lane kept in LDS
 #define RT_SPILL_STACK 104 // deeper entries, per-lane scratch
 #define RT_MAX_STACK (RT_LDS_STACK + RT_SPILL_STACK) // 128, as TLAS.slang:17
+#define RT_CACHE_PAIRS 1536u // breadth-first top of the scene kept in LDS (96 KiB)
 
 #endif

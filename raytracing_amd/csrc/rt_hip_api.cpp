@@ -164,10 +164,72 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   if (f.stack_needed > RT_MAX_STACK)
     return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of " + std::to_string(f.stack_needed) +
                                         " entries; the kernels hold " + std::to_string(RT_MAX_STACK));
+  uint32_t root = f.root_ref;
+  if (root != RT_REF_NONE && !(root & RT_REF_LEAF))
+    root += base;
+  // Renumber so that the top of the scene comes first: breadth-first from the
+  // TLAS root, through instance leaves into each BLAS once, for the first
+  // RT_CACHE_PAIRS records (the LDS-resident set of k_render_v2<.., NCACHE>);
+  // the rest keep their depth-first order behind them.
+  std::vector<rt_dev_inst> insts(f.insts);
+  uint32_t cached = 0;
+  {
+    const uint32_t n = (uint32_t)all.size();
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<uint8_t> seen(n, 0);
+    if (root != RT_REF_NONE) {
+      std::vector<uint32_t> fifo;
+      auto visit = [&](uint32_t ref) {
+        if (ref & RT_REF_LEAF) {
+          if (!(ref & RT_REF_INST))
+            return;
+          ref = insts[ref & 0x3FFFFFFFu].root_ref; // into the BLAS
+          if (ref == RT_REF_NONE || (ref & RT_REF_LEAF))
+            return;
+        }
+        if (!seen[ref]) {
+          seen[ref] = 1;
+          fifo.push_back(ref);
+        }
+      };
+      visit(root);
+      for (size_t head = 0; head < fifo.size() && order.size() < RT_CACHE_PAIRS; ++head) {
+        const uint32_t i = fifo[head];
+        order.push_back(i);
+        visit(all[i].ref0);
+        visit(all[i].ref1);
+      }
+    }
+    cached = (uint32_t)order.size();
+    std::vector<uint8_t> placed(n, 0);
+    for (uint32_t i : order)
+      placed[i] = 1;
+    for (uint32_t i = 0; i < n; ++i)
+      if (!placed[i])
+        order.push_back(i);
+    std::vector<uint32_t> new_index(n);
+    for (uint32_t k = 0; k < n; ++k)
+      new_index[order[k]] = k;
+    auto remap = [&](uint32_t ref) {
+      return (ref == RT_REF_NONE || (ref & RT_REF_LEAF)) ? ref : new_index[ref];
+    };
+    std::vector<rt_dev_pair> sorted(n);
+    for (uint32_t k = 0; k < n; ++k) {
+      rt_dev_pair p = all[order[k]];
+      p.ref0 = remap(p.ref0);
+      p.ref1 = remap(p.ref1);
+      sorted[k] = p;
+    }
+    all.swap(sorted);
+    for (rt_dev_inst &d : insts)
+      d.root_ref = remap(d.root_ref);
+    root = remap(root);
+  }
   int rc;
   if ((rc = upload(ctx, ctx->pairs, all.data(), all.size())) != RT_OK)
     return rc;
-  if ((rc = upload(ctx, ctx->inst_trace, f.insts.data(), f.insts.size())) != RT_OK)
+  if ((rc = upload(ctx, ctx->inst_trace, insts.data(), insts.size())) != RT_OK)
     return rc;
   if ((rc = upload(ctx, ctx->instances, instances, n_inst)) != RT_OK)
     return rc;
@@ -176,10 +238,8 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.pairs = ctx->pairs.ptr;
   ctx->dev.inst_trace = ctx->inst_trace.ptr;
   ctx->dev.instances = ctx->instances.ptr;
-  uint32_t root = f.root_ref;
-  if (root != RT_REF_NONE && !(root & RT_REF_LEAF))
-    root += base;
   ctx->dev.root_ref = root;
+  ctx->dev.cache_pairs = cached;
   return RT_OK;
 }
 
@@ -528,7 +588,7 @@ int rt_reset_stats(rt_ctx *ctx) {
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || (variant & 0xFFu) > 2)
+  if (!ctx || (variant & 0xFFu) > 3)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   // bits 0-7 kernel, 8-15 regen_idle (0 = keep), 16-19 waves/SIMD build of v2 (experiment knobs)
   ctx->variant = variant & 0xFF00FFu;

@@ -23,7 +23,7 @@ struct rt_dev_scene {
   const rt_texture_desc *textures;
   const uint8_t *texels;
   uint32_t root_ref; // TLAS root reference (RT_REF_NONE for an empty scene)
-  uint32_t pad;
+  uint32_t cache_pairs; // pairs[0, cache_pairs) are the breadth-first top of the scene
 };
 
 hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,

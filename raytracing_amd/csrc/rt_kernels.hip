@@ -59,22 +59,23 @@ struct Hit {
 // Per-lane traversal stack: the first RT_LDS_STACK entries live in LDS, laid out
 // [entry][lane] so a wave's accesses to one entry hit 64 consecutive banks;
 // deeper entries (rare) go to per-lane scratch.
-struct Stack {
+template <int BLOCK, int NLDS> struct StackT {
   uint32_t *lds; // &lds_stack[0][tid]
-  uint32_t spill[RT_SPILL_STACK];
+  uint32_t spill[RT_MAX_STACK - NLDS];
   int sp;
   __device__ __forceinline__ void push(uint32_t ref) {
-    if (sp < RT_LDS_STACK)
-      lds[sp * RT_BLOCK] = ref;
+    if (sp < NLDS)
+      lds[sp * BLOCK] = ref;
     else
-      spill[sp - RT_LDS_STACK] = ref;
+      spill[sp - NLDS] = ref;
     ++sp;
   }
   __device__ __forceinline__ uint32_t pop() {
     --sp;
-    return sp < RT_LDS_STACK ? lds[sp * RT_BLOCK] : spill[sp - RT_LDS_STACK];
+    return sp < NLDS ? lds[sp * BLOCK] : spill[sp - NLDS];
   }
 };
+typedef StackT<RT_BLOCK, RT_LDS_STACK> Stack;
 
 // intersect_aabb, BVHNode.slang:8-26 (DIV) / AABB.hpp:29-48 (RCP)
 template <int MODE>
@@ -669,13 +670,32 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 // ---------------------------------------------------------------------------
 enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
-template <int MODE, int MINW>
-__global__ void __launch_bounds__(RT_BLOCK, MINW)
+//
+// NCACHE > 0 (variant 3): the first NCACHE pair records of the scene — the top
+// of the TLAS and of the BLASes, which rt_upload_scene numbers first in
+// breadth-first order — are copied into LDS once per workgroup; every ray
+// walks through them, so about half of all node visits are served by
+// ds_read_b128 (LDS latency, no TA/TD/L1 traffic) instead of four divergent
+// 16-byte global gathers.  One 1024-thread workgroup per CU then owns the
+// whole 160 KiB of LDS: 16 stack entries per lane + 1536 cached records.
+template <int MODE, int MINW, int BLOCK, int NLDS, int NCACHE>
+__global__ void __launch_bounds__(BLOCK, MINW)
     k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
                 uint32_t *__restrict__ queue, uint32_t regen_idle) {
-  __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
-  Stack st;
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  uint32_t *lds_stack = lds_raw;                                                  // [NLDS][BLOCK]
+  const float4 *lds_cache = reinterpret_cast<const float4 *>(lds_raw + NLDS * BLOCK); // [NCACHE][4]
+  uint32_t ncache = 0;
+  if (NCACHE > 0) {
+    ncache = sc.cache_pairs < (uint32_t)NCACHE ? sc.cache_pairs : (uint32_t)NCACHE;
+    float4 *dst = reinterpret_cast<float4 *>(lds_raw + NLDS * BLOCK);
+    const float4 *src = reinterpret_cast<const float4 *>(sc.pairs);
+    for (uint32_t i = threadIdx.x; i < ncache * 4u; i += BLOCK)
+      dst[i] = src[i];
+    __syncthreads();
+  }
+  StackT<BLOCK, NLDS> st;
   st.lds = lds_stack + threadIdx.x;
   st.sp = 0;
   const uint32_t lane = threadIdx.x & 63u;
@@ -779,8 +799,14 @@ __global__ void __launch_bounds__(RT_BLOCK, MINW)
       if (state == ST_TRAVERSE) {
         bool do_pop = false;
         if (!(ref & RT_REF_LEAF)) {
-          const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-          float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          float4 lo0, hi0, lo1, hi1;
+          if (NCACHE > 0 && ref < ncache) {
+            const float4 *q = lds_cache + ref * 4u;
+            lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          } else {
+            const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+            lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          }
           float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
           float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
           uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
@@ -908,24 +934,25 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
       return e;
   }
   const uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
-  auto blocks_for = [&](uint32_t waves_per_simd) { // 4 SIMDs per CU, RT_BLOCK/64 waves per block
-    uint64_t resident = (uint64_t)cus * (waves_per_simd * 4u / (RT_BLOCK / 64u));
-    uint64_t need = (slots + RT_BLOCK - 1) / RT_BLOCK;
+  auto blocks_for = [&](uint32_t waves_per_simd, uint32_t block) { // 4 SIMDs per CU
+    uint64_t resident = (uint64_t)cus * (waves_per_simd * 4u / (block / 64u));
+    uint64_t need = (slots + block - 1) / block;
     return (uint32_t)(need < resident ? need : resident);
   };
-  uint32_t blocks = blocks_for(4);
+  uint32_t blocks = blocks_for(4, RT_BLOCK);
   hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
   if ((variant & 0xFFu) == 1) {
     hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
-  } else {
+  } else if ((variant & 0xFFu) == 2) {
 #define RT_V2(MODE, W)                                                                              \
-  hipLaunchKernelGGL((k_render_v2<MODE, W>), dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,     \
+  hipLaunchKernelGGL((k_render_v2<MODE, W, RT_BLOCK, RT_LDS_STACK, 0>), dim3(blocks), dim3(RT_BLOCK),  \
+                     RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,                                \
                      reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle)
     const uint32_t w = variant >> 16; // experiment knob: min waves per SIMD the kernel is compiled for
-    blocks = blocks_for(w == 0 ? 4 : w);
+    blocks = blocks_for(w == 0 ? 4 : w, RT_BLOCK);
     if (pc.aabb_mode == RT_AABB_RCP) {
       if (w == 5) RT_V2(RT_AABB_RCP, 5);
       else if (w == 6) RT_V2(RT_AABB_RCP, 6);
@@ -936,6 +963,31 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
       else RT_V2(RT_AABB_DIV, 4);
     }
 #undef RT_V2
+  } else {
+    // variant 3: one 1024-thread workgroup per CU owning all 160 KiB of LDS
+    constexpr int B3 = 1024, NL3 = 16, NC3 = 1536;
+    constexpr size_t lds3 = (size_t)NL3 * B3 * 4 + (size_t)NC3 * 64;
+    static_assert(lds3 <= 160 * 1024, "variant 3 LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t ea = hipFuncSetAttribute(
+          reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (ea == hipSuccess)
+        ea = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (ea != hipSuccess)
+        return ea;
+      attr_set = true;
+    }
+    blocks = blocks_for(4, B3);
+    if (pc.aabb_mode == RT_AABB_RCP)
+      hipLaunchKernelGGL((k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+    else
+      hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
   }
   return hipGetLastError();
 }
