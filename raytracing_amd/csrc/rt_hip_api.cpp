@@ -10,6 +10,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_flatten.h"
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 namespace {
 
@@ -75,6 +76,9 @@ struct rt_ctx {
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
+  DevBuf<uint8_t> wf_mem; // path state of the wavefront pipeline (variant 4)
+  uint32_t wf_w = 0, wf_h = 0;
+  uint32_t wf_pair_min = 40, wf_refill_min = 16;
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -310,6 +314,7 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->texels.release();
   ctx->counter.release();
   ctx->queue.release();
+  ctx->wf_mem.release();
   ctx->accum_own.release();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -468,12 +473,28 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (pc.row_begin >= pc.row_end)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty row range");
   HIP_TRY(hipSetDevice(ctx->device));
+  const uint32_t kind = ctx->variant & 0xFFu;
+  const bool wavefront = kind == 4 && pc.max_depth > 0 && pc.max_depth <= 255 &&
+                         (uint64_t)pc.sqrt_spp * pc.sqrt_spp < (1u << 24);
+  if (wavefront) {
+    if (ctx->wf_w != pc.image_width || ctx->wf_h != pc.image_height || !ctx->wf_mem.ptr) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx->wf_mem.reserve(rt_wf_bytes(pc.image_width, pc.image_height)));
+      ctx->wf_w = pc.image_width, ctx->wf_h = pc.image_height;
+    }
+  }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  HIP_TRY(rt_launch_render(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                           ctx->queue.ptr, ctx->regen_idle, ctx->stream));
+  if (wavefront) {
+    rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
+    HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
+                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->stream));
+  } else {
+    HIP_TRY(rt_launch_render(kind == 4 ? 2u : ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum,
+                             ctx->counter.ptr, ctx->queue.ptr, ctx->regen_idle, ctx->stream));
+  }
   return end_timed(ctx, ev);
 }
 
@@ -588,12 +609,16 @@ int rt_reset_stats(rt_ctx *ctx) {
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || (variant & 0xFFu) > 3)
+  if (!ctx || (variant & 0xFFu) > 4)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   // bits 0-7 kernel, 8-15 regen_idle (0 = keep), 16-19 waves/SIMD build of v2 (experiment knobs)
   ctx->variant = variant & 0xFF00FFu;
-  if ((variant >> 8) & 0xFFu)
+  if ((variant >> 8) & 0xFFu) {
     ctx->regen_idle = (variant >> 8) & 0xFFu;
+    ctx->wf_refill_min = (variant >> 8) & 0xFFu;
+  }
+  if ((variant & 0xFFu) == 4 && (variant >> 16)) // variant 4: bits 16.. = pair_min
+    ctx->wf_pair_min = variant >> 16;
   return RT_OK;
 }
 
