@@ -95,6 +95,13 @@ int rt_reset_stats(rt_ctx *ctx);
  * 1: persistent waves with path regeneration.  Same results bit for bit. */
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 
+/* Measurement aid (no counterpart in the reference): every lane of `blocks`
+ * 256-thread workgroups walks the uploaded node records for `steps` dependent,
+ * divergent gathers of `loads` x 16 bytes: the memory-path ceiling of the
+ * traversal kernels.  Returns kernel time and the number of steps walked. */
+int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t loads, double *out_ms,
+                        uint64_t *out_steps);
+
 const char *rt_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only machine; never fails) */
 int rt_device_count(void);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_last_error_string",
+    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_last_error_string",
     "rt_device_count",
 ]
 
@@ -75,6 +75,7 @@ def lib():
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     L.rt_set_kernel_variant.argtypes = [vp, u32]
+    L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
     for name in SYMBOLS:

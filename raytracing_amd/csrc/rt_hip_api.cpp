@@ -78,7 +78,7 @@ struct rt_ctx {
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
   DevBuf<uint8_t> wf_mem; // path state of the wavefront pipeline (variant 4)
   uint32_t wf_w = 0, wf_h = 0;
-  uint32_t wf_pair_min = 40, wf_refill_min = 16;
+  uint32_t wf_pair_min = 40, wf_refill_min = 16, wf_occ = 4;
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -490,7 +490,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (wavefront) {
     rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
-                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->stream));
+                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->stream));
   } else {
     HIP_TRY(rt_launch_render(kind == 4 ? 2u : ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum,
                              ctx->counter.ptr, ctx->queue.ptr, ctx->regen_idle, ctx->stream));
@@ -608,17 +608,48 @@ int rt_reset_stats(rt_ctx *ctx) {
   return RT_OK;
 }
 
+int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t loads, double *out_ms,
+                        uint64_t *out_steps) {
+  if (!ctx || !out_ms || !out_steps || blocks == 0 || loads < 2 || loads > 4)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_probe_walk: bad argument");
+  if (!ctx->have_scene)
+    return fail(RT_ERR_NO_SCENE, "rt_debug_probe_walk: no scene uploaded");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int rc = drain_events(ctx);
+  if (rc != RT_OK)
+    return rc;
+  unsigned long long before = 0, after = 0;
+  HIP_TRY(hipMemcpy(&before, ctx->counter.ptr, sizeof before, hipMemcpyDeviceToHost));
+  EventPair ev;
+  if ((rc = begin_timed(ctx, ev)) != RT_OK)
+    return rc;
+  HIP_TRY(rt_launch_probe_walk(ctx->dev, blocks, steps, loads, ctx->counter.ptr, ctx->stream));
+  if ((rc = end_timed(ctx, ev)) != RT_OK)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if ((rc = drain_events(ctx)) != RT_OK)
+    return rc;
+  HIP_TRY(hipMemcpy(&after, ctx->counter.ptr, sizeof after, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ctx->counter.ptr, &before, sizeof before, hipMemcpyHostToDevice)); // not rays
+  *out_ms = ctx->last_ms;
+  *out_steps = after - before;
+  return RT_OK;
+}
+
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
   if (!ctx || (variant & 0xFFu) > 4)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   // bits 0-7 kernel, 8-15 regen_idle (0 = keep), 16-19 waves/SIMD build of v2 (experiment knobs)
-  ctx->variant = variant & 0xFF00FFu;
+  ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);
   if ((variant >> 8) & 0xFFu) {
     ctx->regen_idle = (variant >> 8) & 0xFFu;
     ctx->wf_refill_min = (variant >> 8) & 0xFFu;
   }
-  if ((variant & 0xFFu) == 4 && (variant >> 16)) // variant 4: bits 16.. = pair_min
-    ctx->wf_pair_min = variant >> 16;
+  if ((variant & 0xFFu) == 4 && ((variant >> 16) & 0xFFu)) // variant 4: bits 16-23 = pair_min
+    ctx->wf_pair_min = (variant >> 16) & 0xFFu;
+  if ((variant & 0xFFu) == 4 && (variant >> 24)) // bits 24.. = waves/SIMD build
+    ctx->wf_occ = variant >> 24;
   return RT_OK;
 }
 

@@ -33,4 +33,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
                             hipStream_t stream);
 
+hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
+                                unsigned long long *d_out, hipStream_t stream);
+
 #endif

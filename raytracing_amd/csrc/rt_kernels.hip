@@ -214,7 +214,7 @@ template <int MODE, int MINW, int BLOCK, int NLDS, int NCACHE>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
-                uint32_t *__restrict__ queue, uint32_t regen_idle) {
+                uint32_t *__restrict__ queue, uint32_t regen_idle, uint32_t nbands_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw;                                                  // [NLDS][BLOCK]
   const float4 *lds_cache = reinterpret_cast<const float4 *>(lds_raw + NLDS * BLOCK); // [NCACHE][4]
@@ -236,6 +236,11 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+
+  // queue bands (wave-uniform)
+  const uint32_t nbands = nbands_arg == 0 ? 1u : nbands_arg;
+  const uint32_t band_slots = (((total_slots >> 6) + nbands - 1u) / nbands) << 6; // whole tiles
+  uint32_t cur_band = blockIdx.x % nbands, bands_tried = 0;
 
   uint32_t state = ST_FETCH;
   uint32_t x = 0, y = 0, sample = 0, depth = 0, traced = 0;
@@ -268,22 +273,36 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         }
       }
     }
-    // ---- (2) lanes without a pixel: pull from the queue (wave-uniform loop) ----
+    // ---- (2) lanes without a pixel: pull from the queues (wave-uniform loop) ----
+    // Eight queues, one per group of workgroups that share an XCD (blockIdx % 8
+    // labels the group): each covers one contiguous band of 8x8 tiles, so an
+    // XCD's 4 MiB L2 sees the rays of one region of the image and of the BVH.
+    // A wave whose band is finished moves on to the next band (work stealing).
     while (true) {
       const bool need = state == ST_FETCH;
       const unsigned long long mask = __ballot(need);
       if (mask == 0ull)
         break;
+      if (bands_tried == nbands) { // every band is empty
+        if (need)
+          state = ST_DONE;
+        break;
+      }
+      const uint32_t band_lo = cur_band * band_slots;
+      const uint32_t band_hi = band_lo + band_slots < total_slots ? band_lo + band_slots : total_slots;
       const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
       uint32_t base = 0;
       if (lane == leader)
-        base = atomicAdd(queue, (uint32_t)__popcll(mask));
-      base = __shfl(base, (int)leader, 64);
+        base = atomicAdd(queue + cur_band, (uint32_t)__popcll(mask));
+      base = __shfl(base, (int)leader, 64) + band_lo;
+      if (base >= band_hi) { // this band is exhausted for everybody: steal from the next one
+        cur_band = cur_band + 1u == nbands ? 0u : cur_band + 1u;
+        ++bands_tried;
+        continue;
+      }
       if (need) {
         const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (slot >= total_slots) {
-          state = ST_DONE;
-        } else {
+        if (slot < band_hi) { // else: retry on the next iteration (band just ran out)
           const uint32_t tile = slot >> 6, in = slot & 63u;
           x = (tile % tiles_x) * 8u + (in & 7u);
           y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
@@ -428,6 +447,57 @@ __global__ void __launch_bounds__(BLOCK, MINW)
 }
 
 // ---------------------------------------------------------------------------
+// k_probe_walk: measurement aid, not part of the render path.  Every lane walks
+// the real pair records from the root, picking a pseudo-random child per step
+// and restarting at the root when it reaches a leaf: the memory access pattern
+// of the traversal (dependent, divergent 64-byte gathers) with almost no
+// arithmetic.  Its step rate is the ceiling the memory path sets for the
+// traversal kernels (roofline).  loads = 1..4 dwordx4 per step.
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+    k_probe_walk(rt_dev_scene sc, uint32_t steps, uint32_t loads, uint32_t start_ref,
+                 unsigned long long *out) {
+  uint32_t ref = start_ref;
+  uint32_t h = (blockIdx.x * RT_BLOCK + threadIdx.x) * 2654435761u + 12345u;
+  float acc = 0.f;
+  unsigned long long walked = 0;
+  for (uint32_t i = 0; i < steps; ++i) {
+    const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+    float4 lo0 = q[0], hi0 = q[1];
+    acc += lo0.x;
+    if (loads > 2) {
+      float4 lo1 = q[2];
+      acc += lo1.y;
+    }
+    if (loads > 3) {
+      float4 hi1 = q[3];
+      acc += hi1.z;
+    }
+    h = h * 1664525u + 1013904223u;
+    uint32_t c = (h >> 16) & 1u ? __float_as_uint(hi0.w) : __float_as_uint(lo0.w);
+    if ((c & (RT_REF_LEAF | RT_REF_INST)) == (RT_REF_LEAF | RT_REF_INST) && c != RT_REF_SENTINEL && c != RT_REF_NONE)
+      c = sc.inst_trace[c & 0x3FFFFFFFu].root_ref; // descend into the instance's BLAS
+    ref = (c & RT_REF_LEAF) ? start_ref : c;
+    ++walked;
+  }
+  if (acc == 123.456f)
+    walked += 1; // keep the loads alive
+  for (int off = 32; off > 0; off >>= 1)
+    walked += __shfl_xor(walked, off, 64);
+  if ((threadIdx.x & 63) == 0)
+    atomicAdd(out, walked);
+}
+
+hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
+                                unsigned long long *d_out, hipStream_t stream) {
+  uint32_t start = sc.root_ref;
+  if (start == RT_REF_NONE || (start & RT_REF_LEAF))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_probe_walk, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, steps, loads, start, d_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Launchers (host).  Shapes are validated by the caller (rt_hip_api.cpp).
 // ---------------------------------------------------------------------------
 hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,
@@ -472,7 +542,8 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     return (uint32_t)(need < resident ? need : resident);
   };
   uint32_t blocks = blocks_for(4, RT_BLOCK);
-  hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
+  const uint32_t nbands = (variant >> 24) ? (variant >> 24) : 1u; // experiment knob: 8 = one band per XCD (measured slower)
+  hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
   if ((variant & 0xFFu) == 1) {
@@ -482,7 +553,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
 #define RT_V2(MODE, W)                                                                              \
   hipLaunchKernelGGL((k_render_v2<MODE, W, RT_BLOCK, RT_LDS_STACK, 0>), dim3(blocks), dim3(RT_BLOCK),  \
                      RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,                                \
-                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle)
+                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands)
     const uint32_t w = variant >> 16; // experiment knob: min waves per SIMD the kernel is compiled for
     blocks = blocks_for(w == 0 ? 4 : w, RT_BLOCK);
     if (pc.aabb_mode == RT_AABB_RCP) {
@@ -516,10 +587,10 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     blocks = blocks_for(4, B3);
     if (pc.aabb_mode == RT_AABB_RCP)
       hipLaunchKernelGGL((k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands);
     else
       hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle);
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands);
   }
   return hipGetLastError();
 }

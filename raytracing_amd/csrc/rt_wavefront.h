@@ -27,6 +27,7 @@ rt_wf_buffers rt_wf_carve(void *mem, uint32_t width, uint32_t height);
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum,
                                       unsigned long long *d_counter, const rt_wf_buffers &b,
-                                      uint32_t pair_min, uint32_t refill_min, hipStream_t stream);
+                                      uint32_t pair_min, uint32_t refill_min, uint32_t occupancy_knob,
+                                      hipStream_t stream);
 
 #endif

@@ -21,8 +21,11 @@
 // Path state lives in HBM between rounds (116 B per pixel, SoA, 16-byte lanes).
 #include "rt_device_inl.h"
 #include "rt_wavefront.h"
+#include <stdio.h>
 
 #pragma clang fp contract(off)
+
+#define RT_WF_CHUNK 256u // rays a wave takes from the round's queue per atomic
 
 namespace {
 
@@ -125,22 +128,28 @@ extern "C" __global__ void __launch_bounds__(256)
 // waiting at leaves (triangles / instances) run once; lanes whose ray is done
 // store the hit and are refilled once `refill_min` of them are idle.
 // ---------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256)
+template <int MODE, int MINW, int NLDS>
+__global__ void __launch_bounds__(256, MINW)
     k_wf_extend(rt_dev_scene sc, rt_wf_buffers b, uint32_t round, uint32_t pair_min,
                 uint32_t refill_min, unsigned long long *ray_counter) {
-  __shared__ uint32_t lds_stack[RT_LDS_STACK * 256];
+  __shared__ uint32_t lds_stack[NLDS * 256];
   const uint32_t nrays = b.count[round % 3u];
   if (nrays == 0)
     return;
   uint32_t *head = b.head + (round & 1u);
   const uint32_t *list = b.list[round & 1u];
-  Stack st;
+  StackT<256, NLDS> st;
   st.lds = lds_stack + threadIdx.x;
   st.sp = 0;
   const uint32_t lane = threadIdx.x & 63u;
 
+#ifdef RT_WF_STATS
+  uint32_t dbg_pair_iters = 0, dbg_pair_lanes = 0, dbg_leaf_iters = 0, dbg_leaf_lanes = 0;
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
   bool active = false, exhausted = false;
+  bool queue_empty = false;               // wave-uniform
+  uint32_t chunk_next = 0, chunk_end = 0; // wave-uniform: this wave's slice of the queue
   uint32_t p = 0, traced = 0;
   V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
   uint32_t ref = RT_REF_NONE, cur_inst = 0;
@@ -150,14 +159,40 @@ __global__ void __launch_bounds__(256)
   hit.t = 0.f, hit.u = hit.v = 0.f, hit.tri = RT_INVALID_ID, hit.inst = RT_INVALID_ID;
 
   while (true) {
-    // ---- refill idle lanes from the queue ----
+    // ---- refill idle lanes from the wave's chunk of the queue ----
+    // One returning atomic per RT_WF_CHUNK rays, not per refill: a single
+    // device-scope head word sustains only ~90 dequeues/us (MI355X_MICROARCH.md,
+    // row 'dequeue'), which at one atomic per 16 rays was the whole round time.
     {
-      const bool want = !active && !exhausted;
-      const uint32_t idx = wave_append(head, want, lane);
-      if (want) {
-        if (idx >= nrays) {
-          exhausted = true;
-        } else {
+      bool want = !active && !exhausted;
+      while (true) {
+        const unsigned long long mask = __ballot(want);
+        if (mask == 0ull)
+          break;
+        if (chunk_next == chunk_end) {
+          if (queue_empty) {
+            if (want)
+              exhausted = true;
+            break;
+          }
+          uint32_t base = 0;
+          if (lane == 0)
+            base = atomicAdd(head, RT_WF_CHUNK);
+          base = __builtin_amdgcn_readfirstlane(base);
+          chunk_next = base < nrays ? base : nrays;
+          chunk_end = base + RT_WF_CHUNK < nrays ? base + RT_WF_CHUNK : nrays;
+          if (chunk_next == chunk_end)
+            queue_empty = true;
+          continue;
+        }
+        const uint32_t avail = chunk_end - chunk_next;
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t n = (uint32_t)__popcll(mask);
+        const bool got = want && rank < avail;
+        const uint32_t idx = chunk_next + rank;
+        chunk_next += n < avail ? n : avail;
+        if (got) {
+          want = false;
           p = list[idx];
           float4 ro = b.ray_o[p], rd = b.ray_d[p];
           o = v3(ro.x, ro.y, ro.z);
@@ -196,6 +231,10 @@ __global__ void __launch_bounds__(256)
           break;
         if ((uint32_t)__popcll(m) < pair_min && __ballot(active && (ref & RT_REF_LEAF)) != 0ull)
           break;
+#ifdef RT_WF_STATS
+        ++dbg_pair_iters;
+        dbg_pair_lanes += (uint32_t)__popcll(m);
+#endif
         if (at_pair) {
           const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
           float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
@@ -230,6 +269,10 @@ __global__ void __launch_bounds__(256)
           }
         }
       }
+#ifdef RT_WF_STATS
+      ++dbg_leaf_iters;
+      dbg_leaf_lanes += (uint32_t)__popcll(__ballot(active && (ref & RT_REF_LEAF)));
+#endif
       // leaf step for the lanes waiting at a leaf
       if (active && (ref & RT_REF_LEAF)) {
         if (ref & RT_REF_INST) {
@@ -304,6 +347,17 @@ __global__ void __launch_bounds__(256)
       ref = RT_REF_NONE; // stored
     }
   }
+#ifdef RT_WF_STATS
+  if (lane == 0) {
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(b.count + 16);
+    atomicAdd(dbg + 0, (unsigned long long)dbg_pair_iters);
+    atomicAdd(dbg + 1, (unsigned long long)dbg_pair_lanes);
+    atomicAdd(dbg + 2, (unsigned long long)dbg_leaf_iters);
+    atomicAdd(dbg + 3, (unsigned long long)dbg_leaf_lanes);
+    atomicAdd(dbg + 4, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_t0));
+    atomicAdd(dbg + 5, 1ull);
+  }
+#endif
   count_rays(ray_counter, traced);
 }
 
@@ -330,9 +384,11 @@ extern "C" __global__ void __launch_bounds__(256)
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp;
   const uint32_t stride = gridDim.x * 256u;
-  // every wave iterates the same number of times so that wave_append stays wave-uniform
-  for (uint32_t base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += stride) {
-    const uint32_t i = base + lane;
+  __shared__ uint32_t wave_total[4], wave_base[4];
+  // every thread of the block iterates the same number of times (barriers inside)
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += stride) {
+    const uint32_t i0 = base + (threadIdx.x & ~63u);
+    const uint32_t i = i0 + lane;
     const bool live = i < n;
     bool again = false;
     uint32_t p = 0;
@@ -379,9 +435,23 @@ extern "C" __global__ void __launch_bounds__(256)
         b.ray_d[p] = make_float4(path.d.x, path.d.y, path.d.z, 0.f);
       }
     }
-    const uint32_t at = wave_append(next_count, again, lane);
+    // block-aggregated compaction: one atomic per 256 paths
+    const unsigned long long mask = __ballot(again);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0)
+      wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t t0 = wave_total[0], t1 = wave_total[1], t2 = wave_total[2], t3 = wave_total[3];
+      const uint32_t total = t0 + t1 + t2 + t3;
+      const uint32_t base_out = total ? atomicAdd(next_count, total) : 0u;
+      wave_base[0] = base_out, wave_base[1] = base_out + t0, wave_base[2] = base_out + t0 + t1;
+      wave_base[3] = base_out + t0 + t1 + t2;
+    }
+    __syncthreads();
     if (again)
-      next_list[at] = p;
+      next_list[wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+    __syncthreads();
   }
 }
 
@@ -417,7 +487,8 @@ rt_wf_buffers rt_wf_carve(void *mem, uint32_t width, uint32_t height) {
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum,
                                       unsigned long long *d_counter, const rt_wf_buffers &b,
-                                      uint32_t pair_min, uint32_t refill_min, hipStream_t stream) {
+                                      uint32_t pair_min, uint32_t refill_min, uint32_t occupancy_knob,
+                                      hipStream_t stream) {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -433,20 +504,36 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
   if (e != hipSuccess)
     return e;
   hipLaunchKernelGGL(k_wf_init, dim3((slots + 255u) / 256u), dim3(256), 0, stream, b, cam, pc);
-  const uint32_t persistent = (uint32_t)cus * 4u; // 4 blocks of 256 threads per CU (VGPR-limited)
+  const uint32_t waves = occupancy_knob == 6 || occupancy_knob == 8 ? occupancy_knob : 4u;
+  const uint32_t persistent = (uint32_t)cus * waves; // blocks of 256 threads per CU = waves per SIMD
   uint32_t grid = (slots + 255u) / 256u;
   if (grid > persistent)
     grid = persistent;
   const uint32_t rounds = pc.sqrt_spp * pc.sqrt_spp * pc.max_depth;
+#define RT_EXT(MODE, W, NL)                                                                         \
+  hipLaunchKernelGGL((k_wf_extend<MODE, W, NL>), dim3(grid), dim3(256), 0, stream, sc, b, r, pair_min, \
+                     refill_min, d_counter)
   for (uint32_t r = 0; r < rounds; ++r) {
-    if (pc.aabb_mode == RT_AABB_RCP)
-      hipLaunchKernelGGL(k_wf_extend<RT_AABB_RCP>, dim3(grid), dim3(256), 0, stream, sc, b, r, pair_min,
-                         refill_min, d_counter);
-    else
-      hipLaunchKernelGGL(k_wf_extend<RT_AABB_DIV>, dim3(grid), dim3(256), 0, stream, sc, b, r, pair_min,
-                         refill_min, d_counter);
+    if (pc.aabb_mode == RT_AABB_RCP) {
+      if (waves == 8) RT_EXT(RT_AABB_RCP, 8, 16);
+      else if (waves == 6) RT_EXT(RT_AABB_RCP, 6, 24);
+      else RT_EXT(RT_AABB_RCP, 4, 24);
+    } else {
+      if (waves == 8) RT_EXT(RT_AABB_DIV, 8, 16);
+      else if (waves == 6) RT_EXT(RT_AABB_DIV, 6, 24);
+      else RT_EXT(RT_AABB_DIV, 4, 24);
+    }
     hipLaunchKernelGGL(k_wf_shade, dim3(grid), dim3(256), 0, stream, sc, b, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), r);
   }
+#undef RT_EXT
+#ifdef RT_WF_STATS
+  {
+    unsigned long long h[6];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, b.count + 16, sizeof h, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[wf stats] pair_iters %llu pair_lanes %llu leaf_iters %llu leaf_lanes %llu wave_cycles %llu waves %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+  }
+#endif
   return hipGetLastError();
 }
