@@ -60,9 +60,13 @@ struct Hit {
 // Per-lane traversal stack: the first RT_LDS_STACK entries live in LDS, laid out
 // [entry][lane] so a wave's accesses to one entry hit 64 consecutive banks;
 // deeper entries (rare) go to per-lane scratch.
+// The spill array is declared by the kernel (RT_STACK_DECL) and only pointed to
+// from here: with the array inside this struct the whole struct — `sp` included —
+// is demoted to scratch memory and every push/pop pays scratch loads and stores.
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr; // typed LDS pointer: ds_read/ds_write, never flat
 template <int BLOCK, int NLDS> struct StackT {
-  uint32_t *lds; // &lds_stack[0][tid]
-  uint32_t spill[RT_MAX_STACK - NLDS];
+  lds_u32_ptr lds; // &lds_stack[0][tid]
+  uint32_t *spill; // per-lane scratch, RT_MAX_STACK - NLDS entries
   int sp;
   __device__ __forceinline__ void push(uint32_t ref) {
     if (sp < NLDS)
@@ -72,11 +76,22 @@ template <int BLOCK, int NLDS> struct StackT {
     ++sp;
   }
   __device__ __forceinline__ uint32_t pop() {
+    // An unconditional ds_read plus a rare scratch branch: `c ? lds[..] : spill[..]`
+    // becomes a select of two pointers and a flat_load on every pop.
     --sp;
-    return sp < NLDS ? lds[sp * BLOCK] : spill[sp - NLDS];
+    uint32_t r = lds[(sp < NLDS ? sp : NLDS - 1) * BLOCK];
+    if (sp >= NLDS)
+      r = spill[sp - NLDS];
+    return r;
   }
 };
 typedef StackT<RT_BLOCK, RT_LDS_STACK> Stack;
+#define RT_STACK_DECL(BLOCK, NLDS, name, lds_base)                                                 \
+  uint32_t name##_spill[RT_MAX_STACK - (NLDS)];                                                    \
+  StackT<BLOCK, NLDS> name;                                                                        \
+  name.lds = (lds_u32_ptr)((lds_base) + threadIdx.x);                                                             \
+  name.spill = name##_spill;                                                                       \
+  name.sp = 0
 
 // intersect_aabb, BVHNode.slang:8-26 (DIV) / AABB.hpp:29-48 (RCP)
 template <int MODE>

@@ -638,9 +638,9 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || (variant & 0xFFu) > 4)
+  if (!ctx || (variant & 0xFFu) > 5)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
-  // bits 0-7 kernel, 8-15 regen_idle (0 = keep), 16-19 waves/SIMD build of v2 (experiment knobs)
+  // bits 0-7 kernel, 8-15 regen_idle (0 = keep); higher bits: per-kernel experiment knobs (rt_kernels.hip)
   ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);
   if ((variant >> 8) & 0xFFu) {
     ctx->regen_idle = (variant >> 8) & 0xFFu;

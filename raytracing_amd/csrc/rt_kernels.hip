@@ -21,8 +21,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
                     rt_hit *__restrict__ hits, uint32_t aabb_mode,
                     unsigned long long *ray_counter) {
   __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
-  Stack st;
-  st.lds = lds_stack + threadIdx.x;
+  RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
   uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
   uint32_t traced = 0;
   if (i < n) {
@@ -58,8 +57,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
     k_render_v0(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter) {
   __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
-  Stack st;
-  st.lds = lds_stack + threadIdx.x;
+  RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
   const uint32_t tiles_x = (pc.image_width + 15u) >> 4;
   const uint32_t tile = xcd_band_tile(blockIdx.x, gridDim.x);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -109,8 +107,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
                 uint32_t *__restrict__ queue) {
   __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
-  Stack st;
-  st.lds = lds_stack + threadIdx.x;
+  RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t rows = pc.row_end - pc.row_begin;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
@@ -200,6 +197,23 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 // next pixel from the queue) and resumes — the unfinished lanes simply carry
 // on.  Per pixel the sequence of arithmetic and RNG draws is unchanged.
 // ---------------------------------------------------------------------------
+#ifdef RT_V2_STATS
+__device__ unsigned long long g_v2_stats[32];
+#define V2_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define V2_ACC(slot, t0, t1) dbg_cyc[slot] += (t1) - (t0)
+#define V2_CNT(slot, pred)                                                                         \
+  do {                                                                                             \
+    const unsigned long long m_ = __ballot(pred);                                                  \
+    if (m_) {                                                                                      \
+      ++dbg_exec[slot];                                                                            \
+      dbg_lanes[slot] += (uint32_t)__popcll(m_);                                                   \
+    }                                                                                              \
+  } while (0)
+#else
+#define V2_T(var)
+#define V2_ACC(slot, t0, t1)
+#define V2_CNT(slot, pred)
+#endif
 enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
 //
@@ -210,14 +224,16 @@ enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, S
 // ds_read_b128 (LDS latency, no TA/TD/L1 traffic) instead of four divergent
 // 16-byte global gathers.  One 1024-thread workgroup per CU then owns the
 // whole 160 KiB of LDS: 16 stack entries per lane + 1536 cached records.
-template <int MODE, int MINW, int BLOCK, int NLDS, int NCACHE>
+template <int MODE, int MINW, int BLOCK, int NLDS, int NCACHE, int SCHED>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
-                uint32_t *__restrict__ queue, uint32_t regen_idle, uint32_t nbands_arg) {
+                uint32_t *__restrict__ queue, uint32_t regen_idle, uint32_t nbands_arg, uint32_t sched_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw;                                                  // [NLDS][BLOCK]
-  const float4 *lds_cache = reinterpret_cast<const float4 *>(lds_raw + NLDS * BLOCK); // [NCACHE][4]
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const f4v *lds_f4_ptr; // typed: ds_read_b128, never flat
+  const lds_f4_ptr lds_cache = (lds_f4_ptr)(lds_raw + NLDS * BLOCK); // [NCACHE][4]
   uint32_t ncache = 0;
   if (NCACHE > 0) {
     ncache = sc.cache_pairs < (uint32_t)NCACHE ? sc.cache_pairs : (uint32_t)NCACHE;
@@ -227,9 +243,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       dst[i] = src[i];
     __syncthreads();
   }
-  StackT<BLOCK, NLDS> st;
-  st.lds = lds_stack + threadIdx.x;
-  st.sp = 0;
+  RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t rows = pc.row_end - pc.row_begin;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
@@ -256,8 +270,16 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   Hit hit;
   hit.t = 0.f, hit.u = hit.v = 0.f, hit.tri = hit.inst = 0;
 
+#ifdef RT_V2_STATS
+  // sections: 0 shade, 1 fetch, 2 newpath, 3 arm, 4 pair, 5 inst, 6 leaf(tri iterations), 7 pop
+  unsigned long long dbg_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t dbg_exec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long dbg_start = __builtin_amdgcn_s_memtime();
+#endif
   while (true) {
     // ---- (1) lanes whose ray is finished: shade, then continue / end the path ----
+    V2_T(ta0);
+    V2_CNT(0, state == ST_SHADE);
     if (state == ST_SHADE) {
       const bool scattered = shade(sc, any, hit, rng, p);
       ++depth;
@@ -273,6 +295,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         }
       }
     }
+    V2_T(ta1);
+    V2_ACC(0, ta0, ta1);
+    V2_CNT(1, state == ST_FETCH);
     // ---- (2) lanes without a pixel: pull from the queues (wave-uniform loop) ----
     // Eight queues, one per group of workgroups that share an XCD (blockIdx % 8
     // labels the group): each covers one contiguous band of 8x8 tiles, so an
@@ -318,6 +343,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     if (__ballot(state != ST_DONE) == 0ull)
       break;
     // ---- (3) new camera ray / next bounce: arm the traversal ----
+    V2_T(ta2);
+    V2_ACC(1, ta1, ta2);
+    V2_CNT(2, state == ST_NEWPATH);
     if (state == ST_NEWPATH) {
       rng.sample = pc.frame_index * spp + sample;
       rng.set_slot(0);
@@ -332,6 +360,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         state = ST_NEWPATH + 100u;
       }
     }
+    V2_T(ta3);
+    V2_ACC(2, ta2, ta3);
+    V2_CNT(3, state == ST_NEWPATH + 100u);
     if (state == ST_NEWPATH + 100u) {
       rng.set_slot(depth + 1);
       ++traced;
@@ -345,85 +376,126 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       st.sp = 0;
       state = ref == RT_REF_NONE ? ST_SHADE : ST_TRAVERSE;
     }
+    V2_T(ta4);
+    V2_ACC(3, ta3, ta4);
+    const uint32_t n_done = (uint32_t)__popcll(__ballot(state == ST_DONE));
+    (void)n_done;
     // ---- (4) traversal steps while enough lanes are traversing ----
-    do {
-      if (state == ST_TRAVERSE) {
+    if (SCHED == 1) {
+      // Vote scheduling (variant 5): each wave iteration runs ONE kind of step —
+      // the one most lanes are waiting for — so the instruction stream of an
+      // iteration is one section at good lane occupancy instead of every section
+      // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
+      // the other kinds wait; per lane the sequence of steps is unchanged.
+      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 1u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 1u;
+      while (true) {
+        const uint32_t kind =
+            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
+        const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
+        const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
+        const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
+        if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
+          break;
+        const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
         bool do_pop = false;
-        if (!(ref & RT_REF_LEAF)) {
-          float4 lo0, hi0, lo1, hi1;
-          if (NCACHE > 0 && ref < ncache) {
-            const float4 *q = lds_cache + ref * 4u;
-            lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-          } else {
-            const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-            lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+        V2_T(tb0);
+        if (s1 >= s2 && s1 >= s3) {
+          V2_CNT(4, kind == 1u);
+          if (kind == 1u) {
+            float4 lo0, hi0, lo1, hi1;
+            if (NCACHE > 0 && ref < ncache) {
+              const lds_f4_ptr q = lds_cache + ref * 4u;
+              {
+                const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+                lo0 = make_float4(a0.x, a0.y, a0.z, a0.w), hi0 = make_float4(a1.x, a1.y, a1.z, a1.w);
+                lo1 = make_float4(a2.x, a2.y, a2.z, a2.w), hi1 = make_float4(a3.x, a3.y, a3.z, a3.w);
+              }
+              asm volatile("" : "+v"(lo0.w)); // keeps the optimiser from merging these with the global loads into flat loads
+            } else {
+              const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+              lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+            }
+            float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+            float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+            uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
+            if (dist1 > dist2) {
+              float tf = dist1;
+              dist1 = dist2;
+              dist2 = tf;
+              uint32_t tc = c1;
+              c1 = c2;
+              c2 = tc;
+            }
+            if (dist1 == kMiss) {
+              do_pop = true;
+            } else {
+              if (dist2 != kMiss)
+                st.push(c2);
+              ref = c1;
+            }
           }
-          float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-          float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-          uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
-          if (dist1 > dist2) {
-            float tf = dist1;
-            dist1 = dist2;
-            dist2 = tf;
-            uint32_t tc = c1;
-            c1 = c2;
-            c2 = tc;
-          }
-          if (dist1 == kMiss) {
-            do_pop = true;
-          } else {
-            if (dist2 != kMiss)
-              st.push(c2);
-            ref = c1;
-          }
-        } else if (ref & RT_REF_INST) {
-          cur_inst = ref & 0x3FFFFFFFu;
-          const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
-          float4 a = q[0], b = q[1], c = q[2], e = q[3];
-          V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
-             c3 = v3(e.x, e.y, e.z);
-          co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
-          cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-          if (MODE == RT_AABB_RCP)
-            cinv = inv_direction(cd);
-          st.push(RT_REF_SENTINEL);
-          ref = __float_as_uint(a.w);
-        } else {
-          uint32_t k = ref & 0x7FFFFFFFu;
-          uint32_t last;
-          do {
+          V2_T(tb1);
+          V2_ACC(4, tb0, tb1);
+        } else if (s3 >= s2) {
+          V2_CNT(6, kind == 3u);
+          if (kind == 3u) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
+            const uint32_t k = ref & 0x7FFFFFFFu;
             const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
             float4 t0 = q[0], t1 = q[1], t2 = q[2];
-            last = __float_as_uint(t1.w);
-            ++k;
+            if (__float_as_uint(t1.w))
+              do_pop = true; // last triangle of the leaf
+            else
+              ref = ref + 1u;
             V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
                edge_2 = v3(t2.x, t2.y, t2.z);
             V3 h = cross(cd, edge_2);
             float a = dot(edge_1, h);
-            if (a > -kEpsilon && a < kEpsilon)
-              continue;
-            float f = 1.f / a;
-            V3 s = co - v0;
-            float u = f * dot(s, h);
-            if (u < 0 || u > 1)
-              continue;
-            V3 qq = cross(s, edge_1);
-            float v = f * dot(cd, qq);
-            if (v < 0 || u + v > 1)
-              continue;
-            float t = f * dot(edge_2, qq);
-            if (t < kEpsilon || !(0.0001f <= t && t <= closest))
-              continue;
-            closest = t;
-            any = true;
-            hit.t = t;
-            hit.u = u;
-            hit.v = v;
-            hit.tri = __float_as_uint(t0.w);
-            hit.inst = cur_inst;
-          } while (!last);
-          do_pop = true;
+            if (!(a > -kEpsilon && a < kEpsilon)) {
+              float f = 1.f / a;
+              V3 s = co - v0;
+              float u = f * dot(s, h);
+              if (!(u < 0 || u > 1)) {
+                V3 qq = cross(s, edge_1);
+                float v = f * dot(cd, qq);
+                if (!(v < 0 || u + v > 1)) {
+                  float t = f * dot(edge_2, qq);
+                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
+                    closest = t;
+                    any = true;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.tri = __float_as_uint(t0.w);
+                    hit.inst = cur_inst;
+                  }
+                }
+              }
+            }
+          }
+          V2_T(tb1);
+          V2_ACC(6, tb0, tb1);
+        } else {
+          V2_CNT(5, kind == 2u);
+          if (kind == 2u) {
+            cur_inst = ref & 0x3FFFFFFFu;
+            const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+            float4 a = q[0], b = q[1], c = q[2], e = q[3];
+            V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
+               c3 = v3(e.x, e.y, e.z);
+            co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
+            cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+            if (MODE == RT_AABB_RCP)
+              cinv = inv_direction(cd);
+            st.push(RT_REF_SENTINEL);
+            ref = __float_as_uint(a.w);
+          }
+          V2_T(tb1);
+          V2_ACC(5, tb0, tb1);
         }
+        V2_T(tb3);
+        V2_CNT(7, do_pop);
         if (do_pop) {
           while (true) {
             if (st.sp == 0) {
@@ -439,10 +511,139 @@ __global__ void __launch_bounds__(BLOCK, MINW)
               cinv = inv_direction(p.d);
           }
         }
+        V2_T(tb4);
+        V2_ACC(7, tb3, tb4);
       }
+    } else
+    do {
+      // one step per traversing lane: 1 = interior pair, 2 = TLAS leaf (enter an instance), 3 = BLAS leaf
+      const uint32_t kind =
+          state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
+      bool do_pop = false;
+      V2_T(tb0);
+      V2_CNT(4, kind == 1u);
+      if (kind == 1u) {
+        float4 lo0, hi0, lo1, hi1;
+        if (NCACHE > 0 && ref < ncache) {
+          const lds_f4_ptr q = lds_cache + ref * 4u;
+          {
+            const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+            lo0 = make_float4(a0.x, a0.y, a0.z, a0.w), hi0 = make_float4(a1.x, a1.y, a1.z, a1.w);
+            lo1 = make_float4(a2.x, a2.y, a2.z, a2.w), hi1 = make_float4(a3.x, a3.y, a3.z, a3.w);
+          }
+          asm volatile("" : "+v"(lo0.w)); // keeps the optimiser from merging these with the global loads into flat loads
+        } else {
+          const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+          lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+        }
+        float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+        float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+        uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
+        if (dist1 > dist2) {
+          float tf = dist1;
+          dist1 = dist2;
+          dist2 = tf;
+          uint32_t tc = c1;
+          c1 = c2;
+          c2 = tc;
+        }
+        if (dist1 == kMiss) {
+          do_pop = true;
+        } else {
+          if (dist2 != kMiss)
+            st.push(c2);
+          ref = c1;
+        }
+      }
+      V2_T(tb1);
+      V2_ACC(4, tb0, tb1);
+      V2_CNT(5, kind == 2u);
+      if (kind == 2u) {
+        cur_inst = ref & 0x3FFFFFFFu;
+        const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+        float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
+           c3 = v3(e.x, e.y, e.z);
+        co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
+        cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+        if (MODE == RT_AABB_RCP)
+          cinv = inv_direction(cd);
+        st.push(RT_REF_SENTINEL);
+        ref = __float_as_uint(a.w);
+      }
+      V2_T(tb2);
+      V2_ACC(5, tb1, tb2);
+      if (kind == 3u) {
+        uint32_t k = ref & 0x7FFFFFFFu;
+        uint32_t last;
+        do {
+          V2_CNT(6, true);
+          const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
+          float4 t0 = q[0], t1 = q[1], t2 = q[2];
+          last = __float_as_uint(t1.w);
+          ++k;
+          V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
+             edge_2 = v3(t2.x, t2.y, t2.z);
+          V3 h = cross(cd, edge_2);
+          float a = dot(edge_1, h);
+          if (a > -kEpsilon && a < kEpsilon)
+            continue;
+          float f = 1.f / a;
+          V3 s = co - v0;
+          float u = f * dot(s, h);
+          if (u < 0 || u > 1)
+            continue;
+          V3 qq = cross(s, edge_1);
+          float v = f * dot(cd, qq);
+          if (v < 0 || u + v > 1)
+            continue;
+          float t = f * dot(edge_2, qq);
+          if (t < kEpsilon || !(0.0001f <= t && t <= closest))
+            continue;
+          closest = t;
+          any = true;
+          hit.t = t;
+          hit.u = u;
+          hit.v = v;
+          hit.tri = __float_as_uint(t0.w);
+          hit.inst = cur_inst;
+        } while (!last);
+        do_pop = true;
+      }
+      V2_T(tb3);
+      V2_ACC(6, tb2, tb3);
+      V2_CNT(7, do_pop);
+      if (do_pop) {
+        while (true) {
+          if (st.sp == 0) {
+            state = ST_SHADE;
+            break;
+          }
+          ref = st.pop();
+          if (ref != RT_REF_SENTINEL)
+            break;
+          co = p.o;
+          cd = p.d;
+          if (MODE == RT_AABB_RCP)
+            cinv = inv_direction(p.d);
+        }
+      }
+      V2_T(tb4);
+      V2_ACC(7, tb3, tb4);
     } while (__ballot(state == ST_TRAVERSE) != 0ull &&
              (uint32_t)__popcll(__ballot(state == ST_SHADE)) < regen_idle);
   }
+#ifdef RT_V2_STATS
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(&g_v2_stats[i], dbg_cyc[i]);
+      atomicAdd(&g_v2_stats[8 + i], (unsigned long long)dbg_exec[i]);
+      atomicAdd(&g_v2_stats[16 + i], (unsigned long long)dbg_lanes[i]);
+    }
+    atomicAdd(&g_v2_stats[24], __builtin_amdgcn_s_memtime() - dbg_start);
+    atomicAdd(&g_v2_stats[25], 1ull);
+  }
+#endif
   count_rays(ray_counter, traced);
 }
 
@@ -542,30 +743,35 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     return (uint32_t)(need < resident ? need : resident);
   };
   uint32_t blocks = blocks_for(4, RT_BLOCK);
-  const uint32_t nbands = (variant >> 24) ? (variant >> 24) : 1u; // experiment knob: 8 = one band per XCD (measured slower)
+  // experiment knobs: variant 2/3 bits 24.. = pixel-queue bands (8 = one per XCD; measured slower);
+  // variant 5 bits 16..27 = vote weights (pair, leaf, instance)
+  const bool vote = (variant & 0xFFu) == 5;
+  const uint32_t nbands = (!vote && (variant >> 24)) ? (variant >> 24) : 1u;
+  const uint32_t sched = vote ? (variant >> 16) & 0xFFFu : 0u;
   hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
   if ((variant & 0xFFu) == 1) {
     hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
-  } else if ((variant & 0xFFu) == 2) {
-#define RT_V2(MODE, W)                                                                              \
-  hipLaunchKernelGGL((k_render_v2<MODE, W, RT_BLOCK, RT_LDS_STACK, 0>), dim3(blocks), dim3(RT_BLOCK),  \
-                     RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,                                \
-                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands)
-    const uint32_t w = variant >> 16; // experiment knob: min waves per SIMD the kernel is compiled for
-    blocks = blocks_for(w == 0 ? 4 : w, RT_BLOCK);
-    if (pc.aabb_mode == RT_AABB_RCP) {
-      if (w == 5) RT_V2(RT_AABB_RCP, 5);
-      else if (w == 6) RT_V2(RT_AABB_RCP, 6);
-      else RT_V2(RT_AABB_RCP, 4);
+  } else if ((variant & 0xFFu) == 2 || (variant & 0xFFu) == 5) {
+#define RT_V2S(MODE, S)                                                                            \
+  hipLaunchKernelGGL((k_render_v2<MODE, 4, RT_BLOCK, RT_LDS_STACK, 0, S>), dim3(blocks),           \
+                     dim3(RT_BLOCK), RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,             \
+                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
+                     sched)
+    if ((variant & 0xFFu) == 5) {
+      if (pc.aabb_mode == RT_AABB_RCP)
+        RT_V2S(RT_AABB_RCP, 1);
+      else
+        RT_V2S(RT_AABB_DIV, 1);
     } else {
-      if (w == 5) RT_V2(RT_AABB_DIV, 5);
-      else if (w == 6) RT_V2(RT_AABB_DIV, 6);
-      else RT_V2(RT_AABB_DIV, 4);
+      if (pc.aabb_mode == RT_AABB_RCP)
+        RT_V2S(RT_AABB_RCP, 0);
+      else
+        RT_V2S(RT_AABB_DIV, 0);
     }
-#undef RT_V2
+#undef RT_V2S
   } else {
     // variant 3: one 1024-thread workgroup per CU owning all 160 KiB of LDS
     constexpr int B3 = 1024, NL3 = 16, NC3 = 1536;
@@ -574,11 +780,11 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t ea = hipFuncSetAttribute(
-          reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3>),
+          reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3, 0>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (ea == hipSuccess)
         ea = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3>),
+            reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3, 0>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (ea != hipSuccess)
         return ea;
@@ -586,11 +792,25 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     }
     blocks = blocks_for(4, B3);
     if (pc.aabb_mode == RT_AABB_RCP)
-      hipLaunchKernelGGL((k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands);
+      hipLaunchKernelGGL((k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3, 0>), dim3(blocks), dim3(B3), lds3, stream,
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands, sched);
     else
-      hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands);
+      hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3, 0>), dim3(blocks), dim3(B3), lds3, stream,
+                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands, sched);
   }
+#ifdef RT_V2_STATS
+  if ((variant & 0xFFu) >= 2) {
+    static const char *names[8] = {"shade", "fetch", "newpath", "arm", "pair", "inst", "leaf", "pop"};
+    unsigned long long h[32], z[32] = {0};
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_v2_stats), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v2_stats), z, sizeof z);
+    fprintf(stderr, "[v2 stats] waves %llu wave_ticks %llu\n", h[25], h[24]);
+    for (int i = 0; i < 8; ++i)
+      fprintf(stderr, "[v2 stats] %-8s ticks %14llu (%5.1f%%) exec %12llu lanes %14llu (%.1f/exec)\n", names[i],
+              h[i], 100.0 * (double)h[i] / (double)(h[24] ? h[24] : 1), h[8 + i], h[16 + i],
+              h[8 + i] ? (double)h[16 + i] / (double)h[8 + i] : 0.0);
+  }
+#endif
   return hipGetLastError();
 }

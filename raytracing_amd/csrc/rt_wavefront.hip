@@ -138,9 +138,7 @@ __global__ void __launch_bounds__(256, MINW)
     return;
   uint32_t *head = b.head + (round & 1u);
   const uint32_t *list = b.list[round & 1u];
-  StackT<256, NLDS> st;
-  st.lds = lds_stack + threadIdx.x;
-  st.sp = 0;
+  RT_STACK_DECL(256, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
 
 #ifdef RT_WF_STATS

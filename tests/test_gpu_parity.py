@@ -90,7 +90,13 @@ def test_empty_scene_misses(ctx):
     assert (got["tri_id"] == T.INVALID_ID).all() and np.array_equal(got["t"], rays["t_max"])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 8) | (64 << 16), 4 | (48 << 8) | (1 << 16)])
+# kernel variants and their schedule knobs (rt_kernels.hip): all must give the same bits
+VARIANTS = [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 8) | (64 << 16),
+            4 | (48 << 8) | (1 << 16), 5, 5 | (1 << 16) | (3 << 20) | (6 << 24), 5 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
+            5 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24)]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name,sqrt_spp,depth,rng", [
     ("cornell", 1, 3, T.RNG_WANG),   # the reference's own launch shape
     ("cornell", 3, 8, T.RNG_WANG),
@@ -118,7 +124,7 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng, variant):
     _same_image(got, want)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 8) | (64 << 16), 4 | (48 << 8) | (1 << 16)])
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_rays_counted_and_rows(ctx, variant):
     sc = S.cornell_builtin().build()
     ctx.upload_scene(sc)
