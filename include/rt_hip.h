@@ -91,8 +91,11 @@ int rt_accum_device_ptr(rt_ctx *ctx, void **out_device_ptr);
 int rt_sync(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);
-/* 0: reference-structured kernel (one lane per pixel, nested loops);
- * 1: persistent waves with path regeneration.  Same results bit for bit. */
+/* Low byte: 0 reference-structured kernel (one lane per pixel, nested loops);
+ * 1 persistent waves with path regeneration; 2 resumable per-lane traversal;
+ * 3 = 2 with an LDS node cache; 4 wavefront pipeline; 5 vote-scheduled traversal
+ * (the default).  Higher bits are schedule knobs (rt_kernels.hip).  Every variant
+ * gives the same results bit for bit. */
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 
 /* Measurement aid (no counterpart in the reference): every lane of `blocks`
@@ -101,6 +104,12 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
  * traversal kernels.  Returns kernel time and the number of steps walked. */
 int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t loads, double *out_ms,
                         uint64_t *out_steps);
+
+/* Test hook (no counterpart in the reference): the exact fast division the slab
+ * test uses for operands of moderate magnitude (rt_device_inl.h, slab_pair_fast)
+ * beside the IEEE n/d, element by element, for host arrays of `count` floats. */
+int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t count, float *q_fast,
+                      float *q_ieee);
 
 const char *rt_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only machine; never fails) */

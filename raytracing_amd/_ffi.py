@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_last_error_string",
+    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_last_error_string",
     "rt_device_count",
 ]
 
@@ -75,6 +75,7 @@ def lib():
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     L.rt_set_kernel_variant.argtypes = [vp, u32]
+    L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -117,6 +118,17 @@ class HipContext:
     def update_instances(self, instances, tlas_nodes, tlas_node_count):
         _check(lib().rt_update_instances(self._h, T.ptr(instances), len(instances),
                                          T.ptr(tlas_nodes), int(tlas_node_count)))
+
+    def debug_fast_div(self, n, d):
+        """(q_fast, q_ieee) of the slab test's exact fast division, elementwise (test hook)."""
+        import numpy as np
+        n = np.ascontiguousarray(n, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        assert n.shape == d.shape and n.ndim == 1
+        q_fast = np.empty_like(n)
+        q_ieee = np.empty_like(n)
+        _check(lib().rt_debug_fast_div(self._h, T.ptr(n), T.ptr(d), n.size, T.ptr(q_fast), T.ptr(q_ieee)))
+        return q_fast, q_ieee
 
     def set_camera(self, cam):
         _check(lib().rt_set_camera(self._h, C.byref(cam)))

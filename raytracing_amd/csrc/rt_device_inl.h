@@ -125,6 +125,102 @@ __device__ __forceinline__ V3 inv_direction(V3 d) {
   return v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 }
 
+// One pair record (rt_dev_pair: x[4], y[4], z[4], refs) as the two child boxes
+// of the reference's formulation: lo/hi of child 0 and 1, child refs in lo0.w / hi0.w.
+__device__ __forceinline__ void unpack_pair(float4 qx, float4 qy, float4 qz, float4 qr, float4 &lo0,
+                                            float4 &hi0, float4 &lo1, float4 &hi1) {
+  lo0 = make_float4(qx.x, qy.x, qz.x, qr.x);
+  hi0 = make_float4(qx.y, qy.y, qz.y, qr.y);
+  lo1 = make_float4(qx.z, qy.z, qz.z, 0.f);
+  hi1 = make_float4(qx.w, qy.w, qz.w, 0.f);
+}
+
+// ---- fast slab test for one pair record, bit-identical to slab<MODE> x2 -------
+// DIV mode.  hipcc lowers an IEEE fp32 `n / d` to
+//   v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup
+// which is correctly rounded.  For operands of moderate magnitude div_scale,
+// div_fmas' scaling and div_fixup are the identity, and what is left is
+//   r1 = fma(fma(-d, rcp(d), 1), rcp(d), rcp(d))            (depends on d only)
+//   q0 = n*r1; e0 = fma(-d,q0,n); q1 = fma(e0,r1,q0); e1 = fma(-d,q1,n); q = fma(e1,r1,q1)
+// The ray's three r1 are computed once per ray space (prep_space), the twelve
+// quotients of a pair record then cost 5 packed-fp32 instructions per two.
+// Preconditions, checked per ray space (fast_axis_ok) and per scene
+// (RT_SCENE_BOXES_MODERATE); a lane that fails them takes slab<MODE>:
+//   2^-30 <= |d| <= 2^30; o == 0 or 2^-66 <= |o| <= 2^59; box coordinate 0 or in
+//   [2^-66, 2^59].  Then every numerator n = b - o is 0 or 2^-90 <= |n| <= 2^60 (a
+//   nonzero difference of two fp32 numbers is at least the smaller ulp), no
+//   intermediate leaves the normal range or loses bits to underflow (fp32
+//   denormals are enabled), and no quotient is NaN — so v_min/v_max/v_min3/v_max3
+//   return what the compare-select min/max of slab<MODE> return, up to the sign
+//   of a zero, which only ever feeds comparisons.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float refined_rcp(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r0, 1.0f);
+  return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ bool fast_axis_ok(float o, float d) {
+  const float ad = fabsf(d), ao = fabsf(o);
+  return ad >= 0x1p-30f && ad <= 0x1p30f && (o == 0.0f || (ao >= 0x1p-66f && ao <= 0x1p59f));
+}
+// RCP mode: inv = 1/d is finite and the numerators are finite, so no product is NaN
+__device__ __forceinline__ bool fast_axis_ok_rcp(float o, float inv) {
+  return fabsf(inv) <= 3.0e38f && fabsf(o) <= 0x1p59f;
+}
+__device__ __forceinline__ f2v div2_exact(f2v n, float d, float r) {
+  const f2v nd = {-d, -d}, rr = {r, r};
+  const f2v q0 = n * rr;
+  const f2v e0 = __builtin_elementwise_fma(nd, q0, n);
+  const f2v q1 = __builtin_elementwise_fma(e0, rr, q0);
+  const f2v e1 = __builtin_elementwise_fma(nd, q1, n);
+  return __builtin_elementwise_fma(e1, rr, q1);
+}
+// Per ray space (world, or an instance's object space): the reciprocals the slab
+// test uses and whether slab_pair_fast may be used.  DIV: inv = refined
+// reciprocals r1 (meaningful when fast); RCP: inv = 1/d.  Plain values, not a
+// struct: a struct handed around by reference ends up in scratch memory.
+template <int MODE>
+__device__ __forceinline__ void prep_space(V3 o, V3 d, bool scene_ok, V3 &inv, bool &fast) {
+  if (MODE == RT_AABB_RCP) {
+    inv = inv_direction(d);
+    fast = scene_ok && fast_axis_ok_rcp(o.x, inv.x) && fast_axis_ok_rcp(o.y, inv.y) &&
+           fast_axis_ok_rcp(o.z, inv.z);
+  } else {
+    inv = v3(refined_rcp(d.x), refined_rcp(d.y), refined_rcp(d.z));
+    fast = scene_ok && fast_axis_ok(o.x, d.x) && fast_axis_ok(o.y, d.y) && fast_axis_ok(o.z, d.z);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void slab_pair_fast(V3 o, V3 d, V3 inv, float4 qx, float4 qy, float4 qz,
+                                               float t, float &dist0, float &dist1) {
+  const f2v ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f2v nx0 = f2v{qx.x, qx.y} - ox, nx1 = f2v{qx.z, qx.w} - ox;
+  const f2v ny0 = f2v{qy.x, qy.y} - oy, ny1 = f2v{qy.z, qy.w} - oy;
+  const f2v nz0 = f2v{qz.x, qz.y} - oz, nz1 = f2v{qz.z, qz.w} - oz;
+  f2v tx0, tx1, ty0, ty1, tz0, tz1;
+  if (MODE == RT_AABB_RCP) {
+    const f2v ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    tx0 = nx0 * ix, tx1 = nx1 * ix;
+    ty0 = ny0 * iy, ty1 = ny1 * iy;
+    tz0 = nz0 * iz, tz1 = nz1 * iz;
+  } else {
+    tx0 = div2_exact(nx0, d.x, inv.x), tx1 = div2_exact(nx1, d.x, inv.x);
+    ty0 = div2_exact(ny0, d.y, inv.y), ty1 = div2_exact(ny1, d.y, inv.y);
+    tz0 = div2_exact(nz0, d.z, inv.z), tz1 = div2_exact(nz1, d.z, inv.z);
+  }
+  const float tmin0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0.x, tx0.y), __builtin_fminf(ty0.x, ty0.y)),
+                                      __builtin_fminf(tz0.x, tz0.y));
+  const float tmax0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0.x, tx0.y), __builtin_fmaxf(ty0.x, ty0.y)),
+                                      __builtin_fmaxf(tz0.x, tz0.y));
+  const float tmin1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1.x, tx1.y), __builtin_fminf(ty1.x, ty1.y)),
+                                      __builtin_fminf(tz1.x, tz1.y));
+  const float tmax1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1.x, tx1.y), __builtin_fmaxf(ty1.x, ty1.y)),
+                                      __builtin_fmaxf(tz1.x, tz1.y));
+  dist0 = (tmax0 >= tmin0 && tmin0 < t && tmax0 > 0) ? tmin0 : kMiss;
+  dist1 = (tmax1 >= tmin1 && tmin1 < t && tmax1 > 0) ? tmin1 : kMiss;
+}
+
 // intersect_tlas (TLAS.slang:14-67) with BLASInstance::intersect
 // (BVHNode.slang:120-128) and BLAS::intersect (:43-109) folded into one loop
 // over one reference stream: pair records for TLAS and BLAS interiors alike,
@@ -148,7 +244,8 @@ __device__ bool trace(const rt_dev_scene &sc, V3 o, V3 d, float tmin, float tmax
     bool do_pop = false;
     if (!(ref & RT_REF_LEAF)) {
       const float4 *p = reinterpret_cast<const float4 *>(sc.pairs + ref);
-      float4 lo0 = p[0], hi0 = p[1], lo1 = p[2], hi1 = p[3];
+      float4 lo0, hi0, lo1, hi1;
+      unpack_pair(p[0], p[1], p[2], p[3], lo0, hi0, lo1, hi1);
       float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
       float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
       uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);

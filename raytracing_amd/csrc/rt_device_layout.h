@@ -19,14 +19,13 @@
 #define RT_REF_SENTINEL 0xFFFFFFFFu // stack marker: BLAS finished, back to world space
 #define RT_REF_NONE 0xFFFFFFFEu     // empty scene
 
-struct alignas(64) rt_dev_pair { // both children of one interior node
-  float min0[3];
-  uint32_t ref0;
-  float max0[3];
+struct alignas(64) rt_dev_pair { // both children of one interior node, one axis per 16 bytes
+  float x[4];    // child0.min.x, child0.max.x, child1.min.x, child1.max.x
+  float y[4];    // the same for y: a dwordx4 load puts (min,max) of one child in one
+  float z[4];    // aligned register pair, which is what the packed-fp32 slab test wants
+  uint32_t ref0; // child references
   uint32_t ref1;
-  float min1[3];
   uint32_t pad0;
-  float max1[3];
   uint32_t pad1;
 };
 

@@ -13,15 +13,14 @@ struct Item {
 };
 
 inline void set_box(rt_dev_pair &p, uint32_t side, const float *mn, const float *mx, uint32_t ref) {
-  if (side == 0) {
-    memcpy(p.min0, mn, 12);
-    memcpy(p.max0, mx, 12);
+  const uint32_t k = side * 2u;
+  p.x[k] = mn[0], p.x[k + 1] = mx[0];
+  p.y[k] = mn[1], p.y[k + 1] = mx[1];
+  p.z[k] = mn[2], p.z[k + 1] = mx[2];
+  if (side == 0)
     p.ref0 = ref;
-  } else {
-    memcpy(p.min1, mn, 12);
-    memcpy(p.max1, mx, 12);
+  else
     p.ref1 = ref;
-  }
 }
 
 std::string at(const char *what, uint64_t i) { return std::string(what) + " " + std::to_string(i); }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <math.h>
 #include <string>
 #include <vector>
 
@@ -230,6 +231,16 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
       d.root_ref = remap(d.root_ref);
     root = remap(root);
   }
+  bool moderate = true; // RT_SCENE_BOXES_MODERATE
+  for (const rt_dev_pair &p : all) {
+    const float *axes[3] = {p.x, p.y, p.z};
+    for (const float *a : axes)
+      for (int k = 0; k < 4; ++k) {
+        const float m = fabsf(a[k]);
+        if (!(m == 0.0f || (m >= 0x1p-66f && m <= 0x1p59f))) // NaN and inf fail too
+          moderate = false;
+      }
+  }
   int rc;
   if ((rc = upload(ctx, ctx->pairs, all.data(), all.size())) != RT_OK)
     return rc;
@@ -244,6 +255,7 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.instances = ctx->instances.ptr;
   ctx->dev.root_ref = root;
   ctx->dev.cache_pairs = cached;
+  ctx->dev.flags = moderate ? RT_SCENE_BOXES_MODERATE : 0u;
   return RT_OK;
 }
 
@@ -634,6 +646,29 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
   HIP_TRY(hipMemcpy(ctx->counter.ptr, &before, sizeof before, hipMemcpyHostToDevice)); // not rays
   *out_ms = ctx->last_ms;
   *out_steps = after - before;
+  return RT_OK;
+}
+
+int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t count, float *q_fast,
+                      float *q_ieee) {
+  if (!ctx || !n || !d || !q_fast || !q_ieee || count > (1ull << 28))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_fast_div: bad argument");
+  if (count == 0)
+    return RT_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  struct Scoped : DevBuf<float> {
+    ~Scoped() { release(); }
+  } bn, bd, bf, bi;
+  HIP_TRY(bn.reserve(count));
+  HIP_TRY(bd.reserve(count));
+  HIP_TRY(bf.reserve(count));
+  HIP_TRY(bi.reserve(count));
+  HIP_TRY(hipMemcpyAsync(bn.ptr, n, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(bd.ptr, d, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(rt_launch_debug_fast_div(bn.ptr, bd.ptr, count, bf.ptr, bi.ptr, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(q_fast, bf.ptr, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(q_ieee, bi.ptr, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 

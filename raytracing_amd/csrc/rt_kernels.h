@@ -9,6 +9,10 @@
 #include "../../include/rt_types.h"
 #include "rt_device_layout.h"
 
+// every box coordinate is 0 or of magnitude in [2^-66, 2^59]: the precondition of the
+// exact fast division of slab_pair_fast (rt_device_inl.h)
+#define RT_SCENE_BOXES_MODERATE 1u
+
 // Device pointers of the flattened scene; passed to kernels by value.
 struct rt_dev_scene {
   const rt_dev_pair *pairs;          // TLAS + BLAS interior records
@@ -24,6 +28,8 @@ struct rt_dev_scene {
   const uint8_t *texels;
   uint32_t root_ref; // TLAS root reference (RT_REF_NONE for an empty scene)
   uint32_t cache_pairs; // pairs[0, cache_pairs) are the breadth-first top of the scene
+  uint32_t flags;       // RT_SCENE_*
+  uint32_t pad;
 };
 
 hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_t n, rt_hit *d_hits,
@@ -35,5 +41,8 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
 
 hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
                                 unsigned long long *d_out, hipStream_t stream);
+
+hipError_t rt_launch_debug_fast_div(const float *d_n, const float *d_d, uint64_t count, float *d_fast,
+                                    float *d_ieee, hipStream_t stream);
 
 #endif

@@ -264,7 +264,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
   // traversal state of the lane's current ray
   uint32_t ref = RT_REF_NONE, cur_inst = 0;
+  // the ray in the space it is being traversed in (prep_space)
   V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
+  bool fast = false;
+  const bool scene_ok = (sc.flags & RT_SCENE_BOXES_MODERATE) != 0u && !(sched_arg & 0x8000u);
   float closest = 0.f;
   bool any = false;
   Hit hit;
@@ -367,9 +370,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       rng.set_slot(depth + 1);
       ++traced;
       ref = sc.root_ref;
-      co = p.o, cd = p.d;
-      if (MODE == RT_AABB_RCP)
-        cinv = inv_direction(p.d);
+      co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
       closest = 1000.f; // RayTracing.slang:93-95
       any = false;
       cur_inst = 0;
@@ -404,22 +405,29 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         if (s1 >= s2 && s1 >= s3) {
           V2_CNT(4, kind == 1u);
           if (kind == 1u) {
-            float4 lo0, hi0, lo1, hi1;
+            float4 qx, qy, qz, qr;
             if (NCACHE > 0 && ref < ncache) {
               const lds_f4_ptr q = lds_cache + ref * 4u;
-              {
-                const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-                lo0 = make_float4(a0.x, a0.y, a0.z, a0.w), hi0 = make_float4(a1.x, a1.y, a1.z, a1.w);
-                lo1 = make_float4(a2.x, a2.y, a2.z, a2.w), hi1 = make_float4(a3.x, a3.y, a3.z, a3.w);
-              }
-              asm volatile("" : "+v"(lo0.w)); // keeps the optimiser from merging these with the global loads into flat loads
+              const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+              qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
+              qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
+              asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
             } else {
               const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-              lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+              qx = q[0], qy = q[1], qz = q[2];
+              const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
+              qr = make_float4(r2.x, r2.y, 0.f, 0.f);
             }
-            float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-            float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-            uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
+            float dist1, dist2;
+            if (fast) {
+              slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
+            } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
+              float4 lo0, hi0, lo1, hi1;
+              unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
+              dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+              dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+            }
+            uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
             if (dist1 > dist2) {
               float tf = dist1;
               dist1 = dist2;
@@ -484,10 +492,8 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             float4 a = q[0], b = q[1], c = q[2], e = q[3];
             V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
                c3 = v3(e.x, e.y, e.z);
-            co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
-            cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-            if (MODE == RT_AABB_RCP)
-              cinv = inv_direction(cd);
+            co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
             st.push(RT_REF_SENTINEL);
             ref = __float_as_uint(a.w);
           }
@@ -505,10 +511,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             ref = st.pop();
             if (ref != RT_REF_SENTINEL)
               break;
-            co = p.o;
-            cd = p.d;
-            if (MODE == RT_AABB_RCP)
-              cinv = inv_direction(p.d);
+            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
           }
         }
         V2_T(tb4);
@@ -523,22 +526,29 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       V2_T(tb0);
       V2_CNT(4, kind == 1u);
       if (kind == 1u) {
-        float4 lo0, hi0, lo1, hi1;
+        float4 qx, qy, qz, qr;
         if (NCACHE > 0 && ref < ncache) {
           const lds_f4_ptr q = lds_cache + ref * 4u;
-          {
-            const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-            lo0 = make_float4(a0.x, a0.y, a0.z, a0.w), hi0 = make_float4(a1.x, a1.y, a1.z, a1.w);
-            lo1 = make_float4(a2.x, a2.y, a2.z, a2.w), hi1 = make_float4(a3.x, a3.y, a3.z, a3.w);
-          }
-          asm volatile("" : "+v"(lo0.w)); // keeps the optimiser from merging these with the global loads into flat loads
+          const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+          qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
+          qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
+          asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
         } else {
           const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-          lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          qx = q[0], qy = q[1], qz = q[2];
+          const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
+          qr = make_float4(r2.x, r2.y, 0.f, 0.f);
         }
-        float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-        float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-        uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);
+        float dist1, dist2;
+        if (fast) {
+          slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
+        } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
+          float4 lo0, hi0, lo1, hi1;
+          unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
+          dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+          dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+        }
+        uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
         if (dist1 > dist2) {
           float tf = dist1;
           dist1 = dist2;
@@ -564,10 +574,8 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         float4 a = q[0], b = q[1], c = q[2], e = q[3];
         V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
            c3 = v3(e.x, e.y, e.z);
-        co = mul_cols(c0, c1, c2, c3, p.o, 1.f);
-        cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-        if (MODE == RT_AABB_RCP)
-          cinv = inv_direction(cd);
+        co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
         st.push(RT_REF_SENTINEL);
         ref = __float_as_uint(a.w);
       }
@@ -622,10 +630,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
           ref = st.pop();
           if (ref != RT_REF_SENTINEL)
             break;
-          co = p.o;
-          cd = p.d;
-          if (MODE == RT_AABB_RCP)
-            cinv = inv_direction(p.d);
+          co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
         }
       }
       V2_T(tb4);
@@ -664,18 +669,18 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
   unsigned long long walked = 0;
   for (uint32_t i = 0; i < steps; ++i) {
     const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-    float4 lo0 = q[0], hi0 = q[1];
+    float4 lo0 = q[0], hi0 = q[3]; // x quad and the refs quad
     acc += lo0.x;
     if (loads > 2) {
-      float4 lo1 = q[2];
+      float4 lo1 = q[1];
       acc += lo1.y;
     }
     if (loads > 3) {
-      float4 hi1 = q[3];
+      float4 hi1 = q[2];
       acc += hi1.z;
     }
     h = h * 1664525u + 1013904223u;
-    uint32_t c = (h >> 16) & 1u ? __float_as_uint(hi0.w) : __float_as_uint(lo0.w);
+    uint32_t c = (h >> 16) & 1u ? __float_as_uint(hi0.y) : __float_as_uint(hi0.x);
     if ((c & (RT_REF_LEAF | RT_REF_INST)) == (RT_REF_LEAF | RT_REF_INST) && c != RT_REF_SENTINEL && c != RT_REF_NONE)
       c = sc.inst_trace[c & 0x3FFFFFFFu].root_ref; // descend into the instance's BLAS
     ref = (c & RT_REF_LEAF) ? start_ref : c;
@@ -687,6 +692,29 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
     walked += __shfl_xor(walked, off, 64);
   if ((threadIdx.x & 63) == 0)
     atomicAdd(out, walked);
+}
+
+// Test hook for the exact fast division of slab_pair_fast: q_fast[i] = div2_exact,
+// q_ieee[i] = the compiler's IEEE n/d, for arbitrary operand pairs.
+extern "C" __global__ void __launch_bounds__(RT_BLOCK)
+    k_debug_fast_div(const float *__restrict__ n, const float *__restrict__ d, uint64_t count,
+                     float *__restrict__ q_fast, float *__restrict__ q_ieee) {
+  const uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+  if (i >= count)
+    return;
+  const float nn = n[i], dd = d[i];
+  const f2v q = div2_exact(f2v{nn, nn}, dd, refined_rcp(dd));
+  q_fast[i] = q.y;
+  q_ieee[i] = nn / dd;
+}
+
+hipError_t rt_launch_debug_fast_div(const float *d_n, const float *d_d, uint64_t count, float *d_fast,
+                                    float *d_ieee, hipStream_t stream) {
+  if (count == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_debug_fast_div, dim3((uint32_t)((count + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0,
+                     stream, d_n, d_d, count, d_fast, d_ieee);
+  return hipGetLastError();
 }
 
 hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
@@ -743,11 +771,11 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     return (uint32_t)(need < resident ? need : resident);
   };
   uint32_t blocks = blocks_for(4, RT_BLOCK);
-  // experiment knobs: variant 2/3 bits 24.. = pixel-queue bands (8 = one per XCD; measured slower);
-  // variant 5 bits 16..27 = vote weights (pair, leaf, instance)
+  // experiment knobs: variant 2/3 bits 24..30 = pixel-queue bands (8 = one per XCD; measured slower);
+  // variant 5 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
   const bool vote = (variant & 0xFFu) == 5;
-  const uint32_t nbands = (!vote && (variant >> 24)) ? (variant >> 24) : 1u;
-  const uint32_t sched = vote ? (variant >> 16) & 0xFFFu : 0u;
+  const uint32_t nbands = (!vote && ((variant >> 24) & 0x7Fu)) ? ((variant >> 24) & 0x7Fu) : 1u;
+  const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u);
   hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;

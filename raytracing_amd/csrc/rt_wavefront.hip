@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(256, MINW)
 #endif
         if (at_pair) {
           const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-          float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+          float4 lo0, hi0, lo1, hi1;
+          unpack_pair(q[0], q[1], q[2], q[3], lo0, hi0, lo1, hi1);
           float dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
           float dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
           uint32_t c1 = __float_as_uint(lo0.w), c2 = __float_as_uint(hi0.w);

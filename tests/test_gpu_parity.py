@@ -172,3 +172,44 @@ def test_bad_input_is_rejected_not_launched(ctx):
         ctx.upload_scene(sc_bad)
     with pytest.raises(_ffi.RtError):
         ctx.trace_closest(S.random_rays(4, 1))  # failed upload leaves no scene
+
+
+@pytest.mark.gpu
+def test_fast_division_is_ieee_division(ctx):
+    """slab_pair_fast's division (rt_device_inl.h: refined reciprocal + two residual
+    corrections, packed fp32) must give the correctly rounded quotient wherever its
+    preconditions hold: |d| in [2^-30, 2^30], n == 0 or |n| in [2^-90, 2^60]."""
+    rs = np.random.RandomState(77)
+    n_rand = 1 << 22
+
+    def rand_floats(count, emin, emax):
+        mant = rs.randint(0, 1 << 23, size=count).astype(np.uint32)
+        expo = rs.randint(emin + 127, emax + 127, size=count).astype(np.uint32)  # emax exclusive
+        sign = rs.randint(0, 2, size=count).astype(np.uint32)
+        return ((sign << 31) | (expo << 23) | mant).view(np.float32)
+
+    d = rand_floats(n_rand, -30, 30)
+    n = rand_floats(n_rand, -90, 60)
+    # adversarial: mantissas of all ones / all zeros, quotients next to rounding boundaries
+    edge_m = np.array([0, 1, 2, 0x7FFFFF, 0x7FFFFE, 0x400000, 0x3FFFFF, 0x555555, 0x2AAAAA], np.uint32)
+    ee = []
+    for ma in edge_m:
+        for mb in edge_m:
+            for ea in (-90, -40, -1, 0, 1, 59):
+                for eb in (-30, -1, 0, 1, 29):
+                    ee.append((((ea + 127) << 23) | int(ma), ((eb + 127) << 23) | int(mb)))
+    ee = np.array(ee, np.uint32)
+    n = np.concatenate([n, ee[:, 0].view(np.float32), -ee[:, 0].view(np.float32), np.zeros(8, np.float32)])
+    d = np.concatenate([d, ee[:, 1].view(np.float32), ee[:, 1].view(np.float32),
+                        np.array([1, -1, 3, -3, 2.0 ** -30, 2.0 ** 29, 0.1, -7e8], np.float32)])
+    # products n = q*d rounded: quotients that sit on or next to representable values
+    q = rand_floats(1 << 20, -20, 20)
+    d2 = rand_floats(1 << 20, -20, 20)
+    n = np.ascontiguousarray(np.concatenate([n, (q * d2).astype(np.float32)]))
+    d = np.ascontiguousarray(np.concatenate([d, d2]))
+    q_fast, q_ieee = ctx.debug_fast_div(n, d)
+    want = (n.astype(np.float32) / d.astype(np.float32)).astype(np.float32)  # numpy fp32 division is IEEE
+    assert np.array_equal(q_ieee.view(np.uint32), want.view(np.uint32))
+    nz = want != 0
+    assert np.array_equal(q_fast.view(np.uint32)[nz], want.view(np.uint32)[nz])
+    assert np.all(q_fast[~nz] == 0)  # the sign of a zero quotient is not part of the contract
