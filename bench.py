@@ -59,6 +59,10 @@ def algorithmic_bytes_per_ray(cn, spp_per_launch):
     return (trav + shade) / rays, 32.0 / spp_per_launch
 
 
+KERNEL_NAMES = {0: "k_render_v0", 1: "k_render_v1", 2: "k_render_v2<SCHED=0>", 3: "k_render_v2<NCACHE=1536>",
+                4: "k_wf_init+k_wf_extend+k_wf_shade", 5: "k_render_v2<SCHED=1>"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +73,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -213,7 +217,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "kernel": "k_render_v%d" % (args.variant & 0xFF), "kernel_ms": kernel_ms,
+                    "kernel": KERNEL_NAMES.get(args.variant & 0xFF, "?"), "kernel_ms": kernel_ms,
                     "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch}
 
     out = {

@@ -96,7 +96,7 @@ struct rt_ctx {
   bool accum_bound = false;
   rt_camera_uniforms camera{};
   bool have_camera = false;
-  uint32_t variant = 2; // persistent, regenerating, resumable-traversal kernel
+  uint32_t variant = 5; // persistent, regenerating, vote-scheduled resumable traversal (k_render_v2<.., SCHED=1>)
   uint32_t regen_idle = 16; // v2: regenerate once this many lanes of a wave are idle
   // timing
   std::vector<EventPair> pending, free_events;

@@ -389,8 +389,8 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
       // the other kinds wait; per lane the sequence of steps is unchanged.
       const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 1u;
-      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 1u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 3u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 6u;
       while (true) {
         const uint32_t kind =
             state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
@@ -776,6 +776,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   const bool vote = (variant & 0xFFu) == 5;
   const uint32_t nbands = (!vote && ((variant >> 24) & 0x7Fu)) ? ((variant >> 24) & 0x7Fu) : 1u;
   const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u);
+  // variant 5 bits 28..30: occupancy build (0: 4 waves/SIMD, 1: 5, 2: 6, 3: 8)
   hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
@@ -789,10 +790,25 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                      reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
                      sched)
     if ((variant & 0xFFu) == 5) {
+      const uint32_t occ = (variant >> 28) & 7u; // experiment knob: waves/SIMD the kernel is built for
+      const uint32_t w = occ == 1 ? 5u : occ == 2 ? 6u : occ == 3 ? 8u : 4u;
+      blocks = blocks_for(w, RT_BLOCK);
+#define RT_V5W(W)                                                                                  \
+  hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, W, RT_BLOCK, RT_LDS_STACK, 0, 1>), dim3(blocks),    \
+                     dim3(RT_BLOCK), RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,             \
+                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
+                     sched)
       if (pc.aabb_mode == RT_AABB_RCP)
         RT_V2S(RT_AABB_RCP, 1);
+      else if (w == 5)
+        RT_V5W(5);
+      else if (w == 6)
+        RT_V5W(6);
+      else if (w == 8)
+        RT_V5W(8);
       else
         RT_V2S(RT_AABB_DIV, 1);
+#undef RT_V5W
     } else {
       if (pc.aabb_mode == RT_AABB_RCP)
         RT_V2S(RT_AABB_RCP, 0);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for the render megakernel, one counter group per run (rocprofv3
 # does not split counters over passes).  Usage: tools/profile_pmc.sh OUTDIR [bench args...]
-# Runs a short bench (one 16-spp 1080p launch by default) per pass.
+# Runs a short bench (one 16-spp 1080p launch by default) per pass.  PASSES="tcc1 tcc2" restricts the passes.
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
 ARGS=${*:-"--steps 1 --warmup 0 --spp 16 --no-cpu-baseline"}
@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 pass() {
   name=$1; shift
+  if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $name "; then return 0; fi
   timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1
   rc=$?
   echo "pass $name rc=$rc"
