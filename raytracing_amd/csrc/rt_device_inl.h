@@ -84,6 +84,28 @@ template <int BLOCK, int NLDS> struct StackT {
       r = spill[sp - NLDS];
     return r;
   }
+  // Variant with the top entry cached in a register (`top`; RT_REF_NONE = bottom marker):
+  // a push is one ds_write, a pop is a register move plus a ds_read whose result is
+  // not needed before the next push/pop, so its latency hides behind the next step.
+  __device__ __forceinline__ void push_top(uint32_t &top, uint32_t ref) {
+    if (sp < NLDS)
+      lds[sp * BLOCK] = top;
+    else
+      spill[sp - NLDS] = top;
+    ++sp;
+    top = ref;
+  }
+  __device__ __forceinline__ uint32_t pop_top(uint32_t &top) { // RT_REF_NONE when the stack is empty
+    const uint32_t r = top;
+    if (r != RT_REF_NONE) { // the marker sits below every pushed entry, so sp >= 1 here
+      --sp;
+      uint32_t t = lds[(sp < NLDS ? sp : NLDS - 1) * BLOCK];
+      if (sp >= NLDS)
+        t = spill[sp - NLDS];
+      top = t;
+    }
+    return r;
+  }
 };
 typedef StackT<RT_BLOCK, RT_LDS_STACK> Stack;
 #define RT_STACK_DECL(BLOCK, NLDS, name, lds_base)                                                 \

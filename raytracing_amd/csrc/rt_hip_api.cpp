@@ -622,7 +622,7 @@ int rt_reset_stats(rt_ctx *ctx) {
 
 int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t loads, double *out_ms,
                         uint64_t *out_steps) {
-  if (!ctx || !out_ms || !out_steps || blocks == 0 || loads < 2 || loads > 4)
+  if (!ctx || !out_ms || !out_steps || blocks == 0 || (loads & 0xFFu) < 2 || (loads & 0xFFu) > 4 || (loads >> 8) > 64)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_probe_walk: bad argument");
   if (!ctx->have_scene)
     return fail(RT_ERR_NO_SCENE, "rt_debug_probe_walk: no scene uploaded");
@@ -673,7 +673,7 @@ int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t coun
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || (variant & 0xFFu) > 5)
+  if (!ctx || (variant & 0xFFu) > 6)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   // bits 0-7 kernel, 8-15 regen_idle (0 = keep); higher bits: per-kernel experiment knobs (rt_kernels.hip)
   ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);

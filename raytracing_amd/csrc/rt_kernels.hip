@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
   // traversal state of the lane's current ray
   uint32_t ref = RT_REF_NONE, cur_inst = 0;
+  uint32_t top = RT_REF_NONE; // SCHED 2: top stack entry (StackT::push_top / pop_top)
   // the ray in the space it is being traversed in (prep_space)
   V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
   bool fast = false;
@@ -375,6 +376,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       any = false;
       cur_inst = 0;
       st.sp = 0;
+      top = RT_REF_NONE;
       state = ref == RT_REF_NONE ? ST_SHADE : ST_TRAVERSE;
     }
     V2_T(ta4);
@@ -382,7 +384,138 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     const uint32_t n_done = (uint32_t)__popcll(__ballot(state == ST_DONE));
     (void)n_done;
     // ---- (4) traversal steps while enough lanes are traversing ----
-    if (SCHED == 1) {
+    if (SCHED == 2) {
+      // Variant 6 = the vote scheduling of variant 5 (below) with the stack top in a register: no pop
+      // section, no pop loop; a sentinel is handled as an instance-space step.
+      // Vote scheduling: each wave iteration runs ONE kind of step —
+      // the one most lanes are waiting for — so the instruction stream of an
+      // iteration is one section at good lane occupancy instead of every section
+      // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
+      // the other kinds wait; per lane the sequence of steps is unchanged.
+      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 3u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 6u;
+      while (true) {
+        const uint32_t kind =
+            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
+        const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
+        const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
+        const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
+        if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
+          break;
+        const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
+        V2_T(tb0);
+        if (s1 >= s2 && s1 >= s3) {
+          V2_CNT(4, kind == 1u);
+          if (kind == 1u) {
+            float4 qx, qy, qz, qr;
+            if (NCACHE > 0 && ref < ncache) {
+              const lds_f4_ptr q = lds_cache + ref * 4u;
+              const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+              qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
+              qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
+              asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
+            } else {
+              const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+              qx = q[0], qy = q[1], qz = q[2];
+              const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
+              qr = make_float4(r2.x, r2.y, 0.f, 0.f);
+            }
+            float dist1, dist2;
+            if (fast) {
+              slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
+            } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
+              float4 lo0, hi0, lo1, hi1;
+              unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
+              dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+              dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+            }
+            uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
+            if (dist1 > dist2) {
+              float tf = dist1;
+              dist1 = dist2;
+              dist2 = tf;
+              uint32_t tc = c1;
+              c1 = c2;
+              c2 = tc;
+            }
+            if (dist1 == kMiss) {
+              ref = st.pop_top(top);
+              if (ref == RT_REF_NONE)
+                state = ST_SHADE;
+            } else {
+              if (dist2 != kMiss)
+                st.push_top(top, c2);
+              ref = c1;
+            }
+          }
+          V2_T(tb1);
+          V2_ACC(4, tb0, tb1);
+        } else if (s3 >= s2) {
+          V2_CNT(6, kind == 3u);
+          if (kind == 3u) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
+            const uint32_t k = ref & 0x7FFFFFFFu;
+            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
+            float4 t0 = q[0], t1 = q[1], t2 = q[2];
+            const bool last = __float_as_uint(t1.w) != 0u; // last triangle of the leaf
+            V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
+               edge_2 = v3(t2.x, t2.y, t2.z);
+            V3 h = cross(cd, edge_2);
+            float a = dot(edge_1, h);
+            if (!(a > -kEpsilon && a < kEpsilon)) {
+              float f = 1.f / a;
+              V3 s = co - v0;
+              float u = f * dot(s, h);
+              if (!(u < 0 || u > 1)) {
+                V3 qq = cross(s, edge_1);
+                float v = f * dot(cd, qq);
+                if (!(v < 0 || u + v > 1)) {
+                  float t = f * dot(edge_2, qq);
+                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
+                    closest = t;
+                    any = true;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.tri = __float_as_uint(t0.w);
+                    hit.inst = cur_inst;
+                  }
+                }
+              }
+            }
+            if (last) {
+              ref = st.pop_top(top);
+              if (ref == RT_REF_NONE)
+                state = ST_SHADE;
+            } else {
+              ref = ref + 1u;
+            }
+          }
+          V2_T(tb1);
+          V2_ACC(6, tb0, tb1);
+        } else {
+          V2_CNT(5, kind == 2u);
+          if (kind == 2u && ref == RT_REF_SENTINEL) { // the instance's BLAS is finished: back to world space
+            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+            ref = st.pop_top(top);
+            if (ref == RT_REF_NONE)
+              state = ST_SHADE;
+          } else if (kind == 2u) {
+            cur_inst = ref & 0x3FFFFFFFu;
+            const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+            float4 a = q[0], b = q[1], c = q[2], e = q[3];
+            V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
+               c3 = v3(e.x, e.y, e.z);
+            co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+            st.push_top(top, RT_REF_SENTINEL);
+            ref = __float_as_uint(a.w);
+          }
+          V2_T(tb1);
+          V2_ACC(5, tb0, tb1);
+        }
+      }
+    } else if (SCHED == 1) {
       // Vote scheduling (variant 5): each wave iteration runs ONE kind of step —
       // the one most lanes are waiting for — so the instruction stream of an
       // iteration is one section at good lane occupancy instead of every section
@@ -667,6 +800,11 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
   uint32_t h = (blockIdx.x * RT_BLOCK + threadIdx.x) * 2654435761u + 12345u;
   float acc = 0.f;
   unsigned long long walked = 0;
+  // loads >> 8: number of lanes per wave that walk (0 = all 64); the others idle, as divergence would
+  const uint32_t live = (loads >> 8) ? (loads >> 8) : 64u;
+  loads &= 0xFFu;
+  if ((threadIdx.x & 63u) >= live)
+    steps = 0;
   for (uint32_t i = 0; i < steps; ++i) {
     const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
     float4 lo0 = q[0], hi0 = q[3]; // x quad and the refs quad
@@ -772,45 +910,57 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   };
   uint32_t blocks = blocks_for(4, RT_BLOCK);
   // experiment knobs: variant 2/3 bits 24..30 = pixel-queue bands (8 = one per XCD; measured slower);
-  // variant 5 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
-  const bool vote = (variant & 0xFFu) == 5;
+  // variants 5/6 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
+  const uint32_t kernel = variant & 0xFFu;
+  const bool vote = kernel == 5 || kernel == 6;
   const uint32_t nbands = (!vote && ((variant >> 24) & 0x7Fu)) ? ((variant >> 24) & 0x7Fu) : 1u;
   const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u);
-  // variant 5 bits 28..30: occupancy build (0: 4 waves/SIMD, 1: 5, 2: 6, 3: 8)
   hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
   if ((variant & 0xFFu) == 1) {
     hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
-  } else if ((variant & 0xFFu) == 2 || (variant & 0xFFu) == 5) {
+  } else if (kernel == 2 || vote) {
+    // experiment knob (variants 5/6, bits 28..30): run at 1..3 waves/SIMD instead of 4 by padding the
+    // workgroup's LDS allocation — measures how much the kernel gains from each extra resident wave
+    size_t lds_bytes = RT_LDS_STACK * RT_BLOCK * 4;
+    const uint32_t occ = vote ? (variant >> 28) & 7u : 0u;
+    if (occ >= 1 && occ <= 3) {
+      lds_bytes = (size_t)(160 * 1024 / occ) - 512;
+      blocks = blocks_for(occ, RT_BLOCK);
+      static bool lds_attr_set = false;
+      if (!lds_attr_set) {
+        const void *fns[] = {reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
+                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 2>),
+                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
+                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, RT_BLOCK, RT_LDS_STACK, 0, 2>)};
+        for (const void *fn : fns) {
+          hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (ea != hipSuccess)
+            return ea;
+        }
+        lds_attr_set = true;
+      }
+    }
 #define RT_V2S(MODE, S)                                                                            \
   hipLaunchKernelGGL((k_render_v2<MODE, 4, RT_BLOCK, RT_LDS_STACK, 0, S>), dim3(blocks),           \
-                     dim3(RT_BLOCK), RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,             \
+                     dim3(RT_BLOCK), lds_bytes, stream, sc, cam, pc,                               \
                      reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
                      sched)
-    if ((variant & 0xFFu) == 5) {
-      const uint32_t occ = (variant >> 28) & 7u; // experiment knob: waves/SIMD the kernel is built for
-      const uint32_t w = occ == 1 ? 5u : occ == 2 ? 6u : occ == 3 ? 8u : 4u;
-      blocks = blocks_for(w, RT_BLOCK);
-#define RT_V5W(W)                                                                                  \
-  hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, W, RT_BLOCK, RT_LDS_STACK, 0, 1>), dim3(blocks),    \
-                     dim3(RT_BLOCK), RT_LDS_STACK * RT_BLOCK * 4, stream, sc, cam, pc,             \
-                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
-                     sched)
-      if (pc.aabb_mode == RT_AABB_RCP)
+    const bool rcp = pc.aabb_mode == RT_AABB_RCP;
+    if (kernel == 6) {
+      if (rcp)
+        RT_V2S(RT_AABB_RCP, 2);
+      else
+        RT_V2S(RT_AABB_DIV, 2);
+    } else if (kernel == 5) {
+      if (rcp)
         RT_V2S(RT_AABB_RCP, 1);
-      else if (w == 5)
-        RT_V5W(5);
-      else if (w == 6)
-        RT_V5W(6);
-      else if (w == 8)
-        RT_V5W(8);
       else
         RT_V2S(RT_AABB_DIV, 1);
-#undef RT_V5W
     } else {
-      if (pc.aabb_mode == RT_AABB_RCP)
+      if (rcp)
         RT_V2S(RT_AABB_RCP, 0);
       else
         RT_V2S(RT_AABB_DIV, 0);

@@ -93,7 +93,8 @@ def test_empty_scene_misses(ctx):
 # kernel variants and their schedule knobs (rt_kernels.hip): all must give the same bits
 VARIANTS = [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 8) | (64 << 16),
             4 | (48 << 8) | (1 << 16), 5, 5 | (1 << 16) | (3 << 20) | (6 << 24), 5 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
-            5 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24)]
+            5 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 6, 6 | (1 << 31), 6 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
+            6 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 5 | (1 << 31), 2 | (1 << 31)]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
