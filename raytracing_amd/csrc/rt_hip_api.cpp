@@ -77,6 +77,8 @@ struct rt_ctx {
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
+  DevBuf<uint8_t> cold;   // per-lane path state of k_render_v7 (variant 7), allocated on first use
+  uint32_t cus = 0;       // compute units of the device
   DevBuf<uint8_t> wf_mem; // path state of the wavefront pipeline (variant 4)
   uint32_t wf_w = 0, wf_h = 0;
   uint32_t wf_pair_min = 40, wf_refill_min = 16, wf_occ = 4;
@@ -326,6 +328,7 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->texels.release();
   ctx->counter.release();
   ctx->queue.release();
+  ctx->cold.release();
   ctx->wf_mem.release();
   ctx->accum_own.release();
   (void)hipStreamDestroy(ctx->stream);
@@ -495,11 +498,26 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       ctx->wf_w = pc.image_width, ctx->wf_h = pc.image_height;
     }
   }
+  if (kind == 7) {
+    if (!ctx->cus) {
+      int cus = 0;
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+      ctx->cus = (uint32_t)cus;
+    }
+    if (!ctx->cold.ptr) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx->cold.reserve(rt_v7_cold_bytes(ctx->cus)));
+    }
+  }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  if (wavefront) {
+  if (kind == 7) {
+    HIP_TRY(rt_launch_render_v7(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
+                                ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
+                                ctx->regen_idle, ctx->stream));
+  } else if (wavefront) {
     rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
                                        ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->stream));
@@ -673,7 +691,7 @@ int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t coun
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
-  if (!ctx || (variant & 0xFFu) > 6)
+  if (!ctx || (variant & 0xFFu) > 7)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   // bits 0-7 kernel, 8-15 regen_idle (0 = keep); higher bits: per-kernel experiment knobs (rt_kernels.hip)
   ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);

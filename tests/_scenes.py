@@ -193,6 +193,33 @@ def mixed_camera(width, height):
     return O.camera_uniforms((3.5, 2.5, 4.5), (0, 0, 0), (0, 1, 0), 45.0, width, height)
 
 
+def edge_scene(kind):
+    """The Cornell scene with one ingredient that puts rays or the whole scene outside the
+    preconditions of the kernels' exact fast slab division (rt_device_inl.h, slab_pair_fast):
+      tiny_vertex  - one box coordinate of magnitude 1e-30: the scene flag RT_SCENE_BOXES_MODERATE is off
+      huge_vertex  - one box coordinate of 1e19 (> 2^59): likewise
+      squashed     - an instance scaled by 1e-10 in x: object-space directions exceed 2^30
+      stretched    - an instance scaled by 1e10 in x: object-space direction components below 2^-30
+    Everything else renders as usual, so the literal slab path runs on real work."""
+    r = cornell_builtin()
+    cube = 1  # add order of cornell_builtin: plane, cube, sphere
+    white = r.add_lambert_material((0.6, 0.6, 0.7))
+    I = (1, 0, 0, 0)
+    if kind in ("tiny_vertex", "huge_vertex"):
+        pos, nrm, uv, idx = plane_mesh()
+        pos = np.array(pos, np.float32).copy()
+        pos.reshape(-1, 3)[0, 1] = 1e-30 if kind == "tiny_vertex" else 1e19
+        b = r.add_blas(pos, nrm, uv, idx)
+        r.add_blas_instance(b, O.trs((0.2, 0.9, 0.2), I, (0.5, 1, 0.5)), white)
+    elif kind == "squashed":
+        r.add_blas_instance(cube, O.trs((0, 1.0, 0.1), I, (1e-10, 0.8, 0.8)), white)
+    elif kind == "stretched":
+        r.add_blas_instance(cube, O.trs((0, 1.2, -0.2), I, (1e10, 0.3, 0.3)), white)
+    else:
+        raise ValueError(kind)
+    return r
+
+
 def random_rays(n, seed, center=(0, 0.3, 0), radius=4.0):
     """Rays from a shell towards a jittered target around `center` (unnormalised
     and axis-aligned directions included: zero components exercise the inf/NaN

@@ -94,7 +94,8 @@ def test_empty_scene_misses(ctx):
 VARIANTS = [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 8) | (64 << 16),
             4 | (48 << 8) | (1 << 16), 5, 5 | (1 << 16) | (3 << 20) | (6 << 24), 5 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
             5 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 6, 6 | (1 << 31), 6 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
-            6 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 5 | (1 << 31), 2 | (1 << 31)]
+            6 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 5 | (1 << 31), 2 | (1 << 31),
+            7, 7 | (2 << 28), 7 | (1 << 31), 7 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24)]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -122,6 +123,33 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng, variant):
     got = ctx.read_accum(w, h)
     ctx.set_kernel_variant(5)  # back to the default
     assert np.isfinite(got).all()
+    _same_image(got, want)
+
+
+@pytest.mark.parametrize("variant", [2, 3, 5, 6, 7])  # the kernels with the fast slab path
+@pytest.mark.parametrize("mode", [T.AABB_DIV, T.AABB_RCP])
+@pytest.mark.parametrize("kind,cam_pos", [
+    ("tiny_vertex", (0, 0.75, 1.5)), ("huge_vertex", (0, 0.75, 1.5)),
+    ("squashed", (0.1, 0.75, 1.5)), ("stretched", (0.1, 0.75, 1.5)),
+    ("squashed", (0, 0.75, 1.5)),        # origin.x exactly 0 (allowed on the fast path)
+    ("squashed", (1e-30, 0.75, 1.5)),    # origin.x tiny but not 0 (not allowed)
+    ("stretched", (0, 1e25, 1.5)),       # origin beyond 2^59
+])
+def test_image_bit_exact_outside_fast_slab_preconditions(ctx, kind, cam_pos, mode, variant):
+    """slab_pair_fast (rt_device_inl.h) may only be used where it is provably the IEEE
+    division; lanes and scenes outside its preconditions must take the literal slab test."""
+    sc = S.edge_scene(kind).build()
+    ctx.upload_scene(sc)
+    ctx.set_kernel_variant(variant)
+    w, h = 72, 40
+    cam = O.camera_uniforms(cam_pos, (0, 0.75, -1), (0, 1, 0), 90.0, w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    p = O.render_params(w, h, 0, 2, 4, aabb_mode=mode)
+    ctx.render(p)
+    want = O.render(sc, cam, p, nthreads=8)
+    got = ctx.read_accum(w, h)
+    ctx.set_kernel_variant(5)  # back to the default
     _same_image(got, want)
 
 
