@@ -103,6 +103,20 @@ const float *rth_mesh_normals(const rth_mesh *m);
 const float *rth_mesh_uvs(const rth_mesh *m);
 const uint32_t *rth_mesh_indices(const rth_mesh *m);
 
+/* Scene files: the reference's JSON scene description (README.md:53-68,
+ * Scenes/TestScene.json; loader semantics of the dead src/Scene.cpp:134-233).
+ * Loads every model of the file into `r` (one BLAS + instance per OBJ material
+ * group) and returns the camera and the image settings of the file.  Returns the
+ * number of triangles added, or a negative rt_status (message: err/err_len). */
+typedef struct rth_scene_info {
+  rth_camera camera;
+  uint32_t screen_width, screen_height;
+  uint32_t samples_per_pixel, max_depth;
+  uint32_t model_count;
+} rth_scene_info;
+int64_t rth_load_scene_file(rth_renderer *r, const char *json_path, rth_scene_info *out, char *err,
+                            int err_len);
+
 /* Builders on their own (tests compare them with the oracle's). */
 uint32_t rth_build_blas(rt_bvh_node *nodes, const rt_triangle_geom *tris, const float *centroids,
                         uint32_t *tri_ids, uint32_t tri_count, uint32_t first);

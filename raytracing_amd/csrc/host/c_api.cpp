@@ -8,6 +8,7 @@
 #include "accel_build.h"
 #include "meshes.h"
 #include "renderer.h"
+#include "scene_file.h"
 
 struct rth_renderer {
   rta::Renderer r;
@@ -236,6 +237,31 @@ int rth_load_obj(const char *path, rth_mesh **groups, float *group_kd, int32_t *
     }
   }
   return n;
+}
+int64_t rth_load_scene_file(rth_renderer *r, const char *json_path, rth_scene_info *out, char *err,
+                            int err_len) {
+  auto fail = [&](const std::string &e) -> int64_t {
+    if (err && err_len > 0)
+      snprintf(err, (size_t)err_len, "%s", e.c_str());
+    return RT_ERR_INVALID_ARGUMENT;
+  };
+  if (!r || !json_path || !out)
+    return fail("NULL argument");
+  rta::SceneFile scene;
+  std::string e;
+  if (!rta::load_scene_file(json_path, scene, e))
+    return fail(e);
+  int64_t tris = rta::instantiate_scene(scene, r->r, e);
+  if (tris < 0)
+    return fail(e);
+  const rta::Camera &c = scene.camera;
+  rth_camera cam = {{c.position.x, c.position.y, c.position.z}, {c.look_at.x, c.look_at.y, c.look_at.z},
+                    {c.v_up.x, c.v_up.y, c.v_up.z}, c.fov, c.defocus_angle, c.focus_dist, 1};
+  out->camera = cam;
+  out->screen_width = scene.screen_width, out->screen_height = scene.screen_height;
+  out->samples_per_pixel = scene.samples_per_pixel, out->max_depth = scene.max_depth;
+  out->model_count = (uint32_t)scene.models.size();
+  return tris;
 }
 void rth_mesh_free(rth_mesh *m) { delete m; }
 uint32_t rth_mesh_vertex_count(const rth_mesh *m) { return m ? (uint32_t)(m->m.positions.size() / 3) : 0; }

@@ -27,7 +27,7 @@ HOST_SYMBOLS = [
     "rth_add_blas_instance", "rth_set_blas_instance_transform", "rth_remove_blas",
     "rth_remove_blas_instance", "rth_primitive_blas", "rth_total_triangle_count", "rth_scene_desc",
     "rth_camera_uniforms", "rth_read_image", "rth_wait", "rth_context", "rth_last_error", "rth_trs",
-    "rth_make_primitive", "rth_make_dragon", "rth_load_obj", "rth_mesh_free", "rth_mesh_vertex_count",
+    "rth_make_primitive", "rth_make_dragon", "rth_load_obj", "rth_load_scene_file", "rth_mesh_free", "rth_mesh_vertex_count",
     "rth_mesh_index_count", "rth_mesh_positions", "rth_mesh_normals", "rth_mesh_uvs",
     "rth_mesh_indices", "rth_build_blas", "rth_build_tlas", "rth_mat4_inverse",
 ]
@@ -37,6 +37,11 @@ class CameraC(C.Structure):  # rth_camera
     _fields_ = [("position", C.c_float * 3), ("look_at", C.c_float * 3), ("v_up", C.c_float * 3),
                 ("fov", C.c_float), ("defocus_angle", C.c_float), ("focus_dist", C.c_float),
                 ("changed", C.c_int32)]
+
+
+class SceneInfoC(C.Structure):  # rth_scene_info
+    _fields_ = [("camera", CameraC), ("screen_width", C.c_uint32), ("screen_height", C.c_uint32),
+                ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32), ("model_count", C.c_uint32)]
 
 
 _LIB = None
@@ -84,6 +89,8 @@ def lib():
     L.rth_make_primitive.argtypes = [C.c_int]; L.rth_make_primitive.restype = vp
     L.rth_make_dragon.argtypes = [u32, u32, u32]; L.rth_make_dragon.restype = vp
     L.rth_load_obj.argtypes = [C.c_char_p, C.POINTER(vp), vp, vp, C.c_int, C.c_char_p, C.c_int]
+    L.rth_load_scene_file.argtypes = [vp, C.c_char_p, C.POINTER(SceneInfoC), C.c_char_p, C.c_int]
+    L.rth_load_scene_file.restype = C.c_int64
     L.rth_mesh_free.argtypes = [vp]; L.rth_mesh_free.restype = None
     for n in ("rth_mesh_vertex_count", "rth_mesh_index_count"):
         getattr(L, n).argtypes = [vp]; getattr(L, n).restype = u32
@@ -287,6 +294,21 @@ class Renderer:
         return lib().rth_get_frame_index(self._h)
 
     # -- beyond the reference -------------------------------------------------
+    def load_scene_file(self, json_path):
+        """Loads a reference scene file (README.md:53-68) into this renderer.  Returns
+        (camera, info) where info has screen_width/height, samples_per_pixel, max_depth,
+        model_count and triangles."""
+        info = SceneInfoC()
+        err = C.create_string_buffer(512)
+        n = lib().rth_load_scene_file(self._h, os.fsencode(json_path), C.byref(info), err, len(err))
+        if n < 0:
+            raise RendererError(err.value.decode(errors="replace"))
+        cam = Camera(info.camera.position, info.camera.look_at, info.camera.v_up, info.camera.fov,
+                     info.camera.defocus_angle, info.camera.focus_dist)
+        return cam, {"screen_width": info.screen_width, "screen_height": info.screen_height,
+                     "samples_per_pixel": info.samples_per_pixel, "max_depth": info.max_depth,
+                     "model_count": info.model_count, "triangles": int(n)}
+
     def set_option(self, option, value):
         self._ok(lib().rth_set_option(self._h, option, value))
 
