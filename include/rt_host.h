@@ -35,7 +35,9 @@ enum rth_option {
   RTH_AABB_MODE = 3,         /* enum rt_aabb_mode */
   RTH_FRAME_STRIDE = 4,      /* multi-GPU sample sharding: RNG frame = offset + k*stride */
   RTH_FRAME_OFFSET = 5,
-  RTH_KERNEL_VARIANT = 6
+  RTH_KERNEL_VARIANT = 6,
+  RTH_ROW_BEGIN = 7, /* multi-GPU row sharding: render rows [begin, end) only; 0,0 = all */
+  RTH_ROW_END = 8
 };
 
 /* Renderer::init / shutdown / resize / render, src/Renderer.cpp:215-652.

@@ -98,6 +98,12 @@ int rth_set_option(rth_renderer *r, int option, uint32_t value) {
   case RTH_FRAME_OFFSET:
     r->r.frame_offset = value;
     break;
+  case RTH_ROW_BEGIN:
+    r->r.row_begin = value;
+    break;
+  case RTH_ROW_END:
+    r->r.row_end = value;
+    break;
   case RTH_KERNEL_VARIANT:
     if (!r->r.context())
       return RT_ERR_NO_DEVICE;

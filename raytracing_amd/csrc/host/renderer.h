@@ -106,6 +106,8 @@ public:
   // frames whose index is congruent to frame_offset modulo frame_stride are
   // rendered by this renderer (multi-GPU sample sharding); defaults: all frames.
   uint32_t frame_stride = 1, frame_offset = 0;
+  // rows [row_begin, row_end) are rendered (multi-GPU row sharding); 0, 0 = the whole image
+  uint32_t row_begin = 0, row_end = 0;
 
   static constexpr size_t MAX_TRIANGLE_COUNT = 4'000'000; // Renderer.cpp:24-26
   static constexpr size_t MAX_MATERIAL_COUNT = 1'000;

@@ -7,6 +7,13 @@ into its own running mean; after k local frames the N-rank image is
 (1/N) * sum_r mean_r  — one sum-reduce of W*H*4 floats per combine over RCCL
 (`torch.distributed` backend "nccl" on ROCm), no collective on the data path
 itself.  The same code runs on CPU tensors with the "gloo" backend.
+
+A second mode shards by image rows instead (`row_shard` / `gather_rows`): rank r
+renders the contiguous row band [begin, end) of every frame through
+rt_render_params.row_begin/row_end and the bands are all-gathered.  No floating
+point is re-associated, so the N-rank image equals the 1-rank image bit for bit;
+the price is load balance (a band of sky finishes early), which is why frames
+are the default for the bench.
 """
 import torch
 import torch.distributed as dist
@@ -40,3 +47,37 @@ def combine(local_mean, out=None, dst=0, group=None):
         out.mul_(1.0 / world)
         return out
     return None
+
+
+def row_shard(rank, world_size, height, align=8):
+    """Row band [begin, end) of rank `rank`: bands are multiples of `align` rows (the
+    kernels fetch 8x8 pixel tiles) except the last, and differ by at most `align`."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    units = (height + align - 1) // align
+    lo = (units * rank) // world_size
+    hi = (units * (rank + 1)) // world_size
+    return min(lo * align, height), min(hi * align, height)
+
+
+def gather_rows(image, rank_rows, group=None):
+    """All-gather the row bands: `image` is this rank's full-size (H, W, C) tensor with
+    its own band filled in; `rank_rows[r]` = (begin, end) of rank r.  Returns the
+    complete image on every rank (in place in `image`)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return image
+    rank = dist.get_rank(group)
+    longest = max(e - b for b, e in rank_rows)
+    if longest == 0:
+        return image
+    shape = (longest,) + tuple(image.shape[1:])
+    mine = torch.zeros(shape, dtype=image.dtype, device=image.device)
+    b, e = rank_rows[rank]
+    mine[: e - b].copy_(image[b:e])
+    parts = [torch.empty(shape, dtype=image.dtype, device=image.device) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    for r, (rb, re) in enumerate(rank_rows):
+        if r != rank and re > rb:
+            image[rb:re].copy_(parts[r][: re - rb])
+    return image

@@ -62,6 +62,51 @@ def test_two_rank_gloo_combine(tmp_path):
     assert (got[..., 3] == 1).all()
 
 
+def _row_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = S.cornell_builtin().build()
+        cam = S.cornell_camera(W, H)
+        bands = [sharding.row_shard(r, world, H) for r in range(world)]
+        img = np.zeros((H, W, 4), np.float32)
+        for f in range(2):  # this rank's band of every frame (the oracle stands in for the GPU)
+            p = O.render_params(W, H, f, SQRT_SPP, DEPTH)
+            p.row_begin, p.row_end = bands[rank]
+            O.render(sc, cam, p, img)
+        full = sharding.gather_rows(torch.from_numpy(img), bands)
+        np.save(out_path % rank, full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_row_bands_equal_single_rank_bitwise(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rows_%d.npy")
+    mp.spawn(_row_worker, args=(2, port, out), nprocs=2, join=True)
+    sc = S.cornell_builtin().build()
+    cam = S.cornell_camera(W, H)
+    single = np.zeros((H, W, 4), np.float32)
+    for f in range(2):
+        O.render(sc, cam, O.render_params(W, H, f, SQRT_SPP, DEPTH), single)
+    for r in range(2):  # every rank ends up with the complete image, bit for bit the 1-rank image
+        assert np.array_equal(np.load(out % r).view(np.uint32), single.view(np.uint32))
+
+
+def test_row_shard_bookkeeping():
+    for h in (1, 7, 8, 9, 24, 1080, 2160):
+        for n in (1, 2, 3, 4, 8):
+            bands = [sharding.row_shard(r, n, h) for r in range(n)]
+            assert bands[0][0] == 0 and bands[-1][1] == h
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(n - 1))
+            assert all(b % 8 == 0 for b, _ in bands)
+    assert [sharding.row_shard(r, 8, 1080) for r in range(8)][3] == (400, 536)
+    with pytest.raises(ValueError):
+        sharding.row_shard(4, 4, 100)
+    x = torch.ones(4, 2, 4)
+    assert sharding.gather_rows(x, [(0, 4)]) is x  # no process group: nothing to gather
+
+
 def test_frame_shard_bookkeeping():
     assert sharding.frame_shard(3, 8) == {"frame_stride": 8, "frame_offset": 3}
     assert sharding.local_frames(1, 4, 10) == [1, 5, 9]
@@ -95,3 +140,35 @@ def test_frame_sharding_through_renderer_on_one_gpu():
         assert np.array_equal(means[-1].view(np.uint32), want.view(np.uint32))
         r.shutdown()
     assert not np.array_equal(means[0], means[1])
+
+
+@pytest.mark.gpu
+def test_row_sharding_through_renderer_on_one_gpu():
+    """Two renderers play two ranks of the row-band mode: the stitched image is the
+    single-renderer image bit for bit."""
+    from raytracing_amd import renderer as R
+    from .test_host_parity import _cornell_via_product
+    cam = R.Camera((0, 0.75, 1.5), (0, 0.75, -1), (0, 1, 0), 90.0)
+    bands = [sharding.row_shard(k, 2, H) for k in range(2)]
+    stitched = np.zeros((H, W, 4), np.float32)
+    for rank in range(2):
+        r = _cornell_via_product(device=0, w=W, h=H)
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, SQRT_SPP * SQRT_SPP)
+        r.set_option(R.OPT_MAX_DEPTH, DEPTH)
+        r.set_option(R.OPT_ROW_BEGIN, bands[rank][0])
+        r.set_option(R.OPT_ROW_END, bands[rank][1])
+        for _ in range(2):
+            r.render(cam)
+        img = r.read_image()
+        b, e = bands[rank]
+        stitched[b:e] = img[b:e]
+        assert (np.delete(img, np.s_[b:e], axis=0) == 0).all()  # rows outside the band are untouched
+        r.shutdown()
+    r = _cornell_via_product(device=0, w=W, h=H)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, SQRT_SPP * SQRT_SPP)
+    r.set_option(R.OPT_MAX_DEPTH, DEPTH)
+    for _ in range(2):
+        r.render(cam)
+    single = r.read_image()
+    r.shutdown()
+    assert np.array_equal(stitched.view(np.uint32), single.view(np.uint32))
