@@ -640,7 +640,7 @@ int rt_reset_stats(rt_ctx *ctx) {
 
 int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t loads, double *out_ms,
                         uint64_t *out_steps) {
-  if (!ctx || !out_ms || !out_steps || blocks == 0 || (loads & 0xFFu) < 2 || (loads & 0xFFu) > 4 || (loads >> 8) > 64)
+  if (!ctx || !out_ms || !out_steps || blocks == 0 || (loads & 0xFFu) < 2 || (loads & 0xFFu) > 5 || (loads >> 8) > 64)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_probe_walk: bad argument");
   if (!ctx->have_scene)
     return fail(RT_ERR_NO_SCENE, "rt_debug_probe_walk: no scene uploaded");

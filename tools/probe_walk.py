@@ -10,11 +10,9 @@ cam, n = bench.build_dragon_scene(R, r)
 r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1)
 r.render(cam); r.wait()   # uploads the scene
 ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
-for blocks_per_cu in (4,):
-    for live in (64, 48, 32, 16, 8):
-        for loads in (2, 4):
-            ms, steps = C.c_double(), C.c_uint64()
-            for _ in range(2):
-                _ffi._check(L.rt_debug_probe_walk(ctx, 256 * blocks_per_cu, 2000, loads | (live << 8), C.byref(ms), C.byref(steps)))
-            print(f"waves/SIMD {blocks_per_cu} live lanes {live} loads {loads}x16B: {steps.value/ms.value/1e6:8.1f} G steps/s, "
-                  f"{steps.value/ms.value/1e6*loads*16/1e3:6.2f} TB/s useful, {ms.value:.2f} ms")
+for blocks_per_cu in (2, 4, 8):
+    for loads, name in ((4, "4x16B per lane"), (5, "quad-cooperative 64B")):
+        ms, steps = C.c_double(), C.c_uint64()
+        for _ in range(2):
+            _ffi._check(L.rt_debug_probe_walk(ctx, 256 * blocks_per_cu, 2000, loads, C.byref(ms), C.byref(steps)))
+        print(f"waves/SIMD {blocks_per_cu} {name}: {steps.value/ms.value/1e6:8.1f} G steps/s, {ms.value:.2f} ms")
