@@ -293,6 +293,12 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
     e = ctx->queue.reserve(64);
   if (e == hipSuccess)
     e = hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream);
+  int cus = 0;
+  if (e == hipSuccess)
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+  ctx->cus = (uint32_t)(cus > 0 ? cus : 0);
+  if (e == hipSuccess && ctx->cus == 0)
+    e = hipErrorInvalidDevice;
   if (e != hipSuccess) {
     delete ctx;
     return fail(RT_ERR_HIP, std::string("rt_create: ") + hipGetErrorString(e));
@@ -499,11 +505,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     }
   }
   if (kind == 7) {
-    if (!ctx->cus) {
-      int cus = 0;
-      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-      ctx->cus = (uint32_t)cus;
-    }
     if (!ctx->cold.ptr) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       HIP_TRY(ctx->cold.reserve(rt_v7_cold_bytes(ctx->cus)));
@@ -520,10 +521,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   } else if (wavefront) {
     rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
-                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->stream));
+                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->cus, ctx->stream));
   } else {
     HIP_TRY(rt_launch_render(kind == 4 ? 2u : ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum,
-                             ctx->counter.ptr, ctx->queue.ptr, ctx->regen_idle, ctx->stream));
+                             ctx->counter.ptr, ctx->queue.ptr, ctx->regen_idle, ctx->cus, ctx->stream));
   }
   return end_timed(ctx, ev);
 }

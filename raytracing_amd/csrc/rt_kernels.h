@@ -37,7 +37,7 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
-                            hipStream_t stream);
+                            uint32_t cus, hipStream_t stream);
 
 // rt_render_v7.hip: low-register vote-scheduled kernel; d_cold holds rt_v7_cold_bytes(cus) bytes
 size_t rt_v7_cold_bytes(uint32_t cus);

@@ -8,6 +8,8 @@
 // Bit-exactness contract with the oracle: fp32, no FMA contraction (file-wide
 // pragma + -ffp-contract=off), IEEE divide/sqrt (hipcc default), explicit
 // compare-select min/max, the oracle's operation order everywhere.
+#include <atomic>
+
 #include "rt_device_inl.h"
 
 #pragma clang fp contract(off)
@@ -907,10 +909,24 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
   return hipGetLastError();
 }
 
+// hipFuncSetAttribute is per device: remember per (device, attribute group) whether it was done.
+static std::atomic<uint64_t> g_attr_done[2];
+static bool attr_done_on_this_device(int group) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < 64 && ((g_attr_done[group].load() >> dev) & 1ull);
+}
+static void mark_attr_done_on_this_device(int group) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64)
+    g_attr_done[group].fetch_or(1ull << dev);
+}
+
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
-                            hipStream_t stream) {
+                            uint32_t cus, hipStream_t stream) {
   uint32_t rows = pc.row_end - pc.row_begin;
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
@@ -920,16 +936,9 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                        reinterpret_cast<float4 *>(d_accum), d_counter);
     return hipGetLastError();
   }
-  // persistent grid: only as many blocks as the chip holds at once
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess)
-      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess)
-      return e;
-  }
+  // persistent grid: only as many blocks as the chip holds at once (cus = compute units of the device)
+  if (cus == 0)
+    return hipErrorInvalidValue;
   const uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
   auto blocks_for = [&](uint32_t waves_per_simd, uint32_t block) { // 4 SIMDs per CU
     uint64_t resident = (uint64_t)cus * (waves_per_simd * 4u / (block / 64u));
@@ -957,8 +966,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     if (occ >= 1 && occ <= 3) {
       lds_bytes = (size_t)(160 * 1024 / occ) - 512;
       blocks = blocks_for(occ, RT_BLOCK);
-      static bool lds_attr_set = false;
-      if (!lds_attr_set) {
+      if (!attr_done_on_this_device(0)) {
         const void *fns[] = {reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
                              reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 2>),
                              reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
@@ -968,7 +976,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
           if (ea != hipSuccess)
             return ea;
         }
-        lds_attr_set = true;
+        mark_attr_done_on_this_device(0);
       }
     }
 #define RT_V2S(MODE, S)                                                                            \
@@ -999,8 +1007,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     constexpr int B3 = 1024, NL3 = 16, NC3 = 1536;
     constexpr size_t lds3 = (size_t)NL3 * B3 * 4 + (size_t)NC3 * 64;
     static_assert(lds3 <= 160 * 1024, "variant 3 LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!attr_done_on_this_device(1)) {
       hipError_t ea = hipFuncSetAttribute(
           reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3, 0>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
@@ -1010,7 +1017,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (ea != hipSuccess)
         return ea;
-      attr_set = true;
+      mark_attr_done_on_this_device(1);
     }
     blocks = blocks_for(4, B3);
     if (pc.aabb_mode == RT_AABB_RCP)

@@ -28,6 +28,6 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
                                       const rt_render_params &pc, float *d_accum,
                                       unsigned long long *d_counter, const rt_wf_buffers &b,
                                       uint32_t pair_min, uint32_t refill_min, uint32_t occupancy_knob,
-                                      hipStream_t stream);
+                                      uint32_t cus, hipStream_t stream);
 
 #endif

@@ -487,16 +487,9 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
                                       const rt_render_params &pc, float *d_accum,
                                       unsigned long long *d_counter, const rt_wf_buffers &b,
                                       uint32_t pair_min, uint32_t refill_min, uint32_t occupancy_knob,
-                                      hipStream_t stream) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess)
-      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess)
-      return e;
-  }
+                                      uint32_t cus, hipStream_t stream) {
+  if (cus == 0)
+    return hipErrorInvalidValue;
   const uint32_t rows = pc.row_end - pc.row_begin;
   const uint32_t slots = ((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
   hipError_t e = hipMemsetAsync(b.count, 0, 256, stream);
