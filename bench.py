@@ -139,6 +139,8 @@ def main():
                 sharding.gather_rows(accum, bands)       # every rank: the complete image, bit-exact
             else:
                 sharding.combine(accum, out=reduced, dst=0)  # rank 0: (1/N) * sum of the N running means
+            # the collective reads `accum` on torch's stream; the next launch writes it on the library's
+            torch.cuda.current_stream().synchronize()
 
     def fence():
         r.wait()
