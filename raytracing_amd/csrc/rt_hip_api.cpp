@@ -99,7 +99,8 @@ struct rt_ctx {
   rt_camera_uniforms camera{};
   bool have_camera = false;
   uint32_t variant = 5; // persistent, regenerating, vote-scheduled resumable traversal (k_render_v2<.., SCHED=1>)
-  uint32_t regen_idle = 16; // v2: regenerate once this many lanes of a wave are idle
+  uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
+  uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
   // timing
   std::vector<EventPair> pending, free_events;
   double total_ms = 0.0, last_ms = 0.0;
@@ -257,6 +258,7 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.instances = ctx->instances.ptr;
   ctx->dev.root_ref = root;
   ctx->dev.cache_pairs = cached;
+  ctx->pair_count = (uint32_t)all.size();
   ctx->dev.flags = moderate ? RT_SCENE_BOXES_MODERATE : 0u;
   return RT_OK;
 }
@@ -469,6 +471,17 @@ int rt_clear_accum(rt_ctx *ctx) {
   return RT_OK;
 }
 
+// Regeneration threshold of the persistent kernels when the caller set none.  Measured
+// (tools/bench_lowspp.py): small scenes, whose rays finish within a few steps of each other, want
+// rare, well-filled regeneration phases (48 idle lanes: Cornell 1280x720 1 spp 1.02 -> 0.58 ms,
+// 64 spp 38.6 -> 36.5 ms); deep trees, whose rays finish far apart, want early ones (16: C3
+// 75 ms vs 84 ms at 48).
+static uint32_t effective_regen_idle(const rt_ctx *ctx) {
+  if (ctx->regen_idle)
+    return ctx->regen_idle;
+  return ctx->pair_count <= 16384u ? 48u : 16u;
+}
+
 int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (!ctx || !params)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
@@ -517,14 +530,14 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (kind == 7) {
     HIP_TRY(rt_launch_render_v7(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
                                 ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
-                                ctx->regen_idle, ctx->stream));
+                                effective_regen_idle(ctx), ctx->stream));
   } else if (wavefront) {
     rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
                                        ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->cus, ctx->stream));
   } else {
     HIP_TRY(rt_launch_render(kind == 4 ? 2u : ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum,
-                             ctx->counter.ptr, ctx->queue.ptr, ctx->regen_idle, ctx->cus, ctx->stream));
+                             ctx->counter.ptr, ctx->queue.ptr, effective_regen_idle(ctx), ctx->cus, ctx->stream));
   }
   return end_timed(ctx, ev);
 }
@@ -694,12 +707,11 @@ int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t coun
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
   if (!ctx || (variant & 0xFFu) > 7)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
-  // bits 0-7 kernel, 8-15 regen_idle (0 = keep); higher bits: per-kernel experiment knobs (rt_kernels.hip)
+  // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: per-kernel experiment knobs (rt_kernels.hip)
   ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);
-  if ((variant >> 8) & 0xFFu) {
-    ctx->regen_idle = (variant >> 8) & 0xFFu;
+  ctx->regen_idle = (variant >> 8) & 0xFFu; // 0: chosen by scene size (effective_regen_idle)
+  if ((variant >> 8) & 0xFFu)
     ctx->wf_refill_min = (variant >> 8) & 0xFFu;
-  }
   if ((variant & 0xFFu) == 4 && ((variant >> 16) & 0xFFu)) // variant 4: bits 16-23 = pair_min
     ctx->wf_pair_min = (variant >> 16) & 0xFFu;
   if ((variant & 0xFFu) == 4 && (variant >> 24)) // bits 24.. = waves/SIMD build
