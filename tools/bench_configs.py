@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""The BASELINE configs beside C3 (which bench.py measures), on one GPU, default kernel:
+C1 Cornell OBJ scene file, C2 teapot, C4 2025 transformed instances, C5 camera (defocus) on C3."""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+import bench
+from raytracing_amd import _ffi, renderer as R
+from tests import _scenes as S
+
+def measure(r, cam, spp, depth, frames=3):
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, spp)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.render(cam); r.wait()
+    ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
+    _ffi._check(L.rt_reset_stats(ctx))
+    for _ in range(frames):
+        r.render(cam)
+    r.wait()
+    st = _ffi.Stats(); _ffi._check(L.rt_get_stats(ctx, C.byref(st)))
+    return st.total_kernel_ms / frames, st.rays_traced / st.total_kernel_ms / 1e3, r.total_triangle_count
+
+W, H = 1920, 1080
+rows = []
+# C1: the shipped scene file (Cornell box OBJ, scale 3), sky lit
+r = R.Renderer(W, H, device=0)
+cam, info = r.load_scene_file(os.path.join(S.ASSETS, "scenes", "cornell.json"))
+rows.append(("C1 CornellBox-Original.obj via scene file, 64 spp, depth 8",) + measure(r, cam, 64, 8))
+r.shutdown()
+# C2: teapot
+r = R.Renderer(W, H, device=0)
+cam, info = r.load_scene_file(os.path.join(S.ASSETS, "scenes", "teapot.json"))
+rows.append(("C2 teapot.obj, 64 spp, depth 8",) + measure(r, cam, 64, 8))
+r.shutdown()
+# C4: 45 x 45 instances of teapot / sphere / cube, mixed materials (the parity test's scene class)
+r = R.Renderer(W, H, device=0)
+rng = np.random.default_rng(7)
+(tea, _, _), = R.Mesh.load_obj(os.path.join(S.ASSETS, "teapot.obj"))
+blases = [r.cube_blas_index, r.sphere_blas_index, r.add_blas(tea)]
+mats = [r.default_material, r.add_lambert_material((0.8, 0.3, 0.2)), r.add_metal_material((0.8, 0.8, 0.9), 0.05),
+        r.add_metal_material((0.9, 0.6, 0.2), 0.4), r.add_dielectric_material(1.5), r.add_emissive_material((4.0, 3.5, 3.0))]
+r.add_blas_instance(r.plane_blas_index, R.trs((0, -0.5, 0), 0.0, (0, 1, 0), (120, 1, 120)), mats[1])
+n_side, k = 45, 0
+for iz in range(n_side):
+    for ix in range(n_side):
+        p = ((ix - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2), rng.uniform(0.0, 0.4),
+             (iz - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2))
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        s = rng.uniform(0.6, 1.1)
+        r.add_blas_instance(blases[k % 3], R.trs(p, float(rng.uniform(0, 2 * math.pi)), tuple(axis), (s, s, s)), mats[k % 6])
+        k += 1
+cam = R.Camera((30, 22, 40), (0, 0, 0), (0, 1, 0), 45.0)
+rows.append(("C4 2025 instances (teapot/sphere/cube, 4 material types), 64 spp, depth 8",) + measure(r, cam, 64, 8))
+r.shutdown()
+# C5 camera on the C3 scene: defocus blur, 3840 wide
+r = R.Renderer(3840, 2160, device=0)
+cam, _ = bench.build_dragon_scene(R, r)
+cam.c.defocus_angle, cam.c.focus_dist = 0.8, 4.2
+rows.append(("C5 dragon stand-in 3840x2160 with defocus blur, 64 spp, depth 8 (one GPU)",) + measure(r, cam, 64, 8, frames=2))
+r.shutdown()
+for name, ms, mrays, tris in rows:
+    print(f"{name}: {tris} triangles (incl. primitives), {ms:.1f} ms per launch, {mrays:.0f} Mrays/s")
