@@ -440,19 +440,19 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Rng &rng) { // Random.slang:57-6
 }
 
 // nearest / repeat RGBA8-UNORM fetch (Renderer.cpp:347-361, Material.cpp:170)
-__device__ __forceinline__ V3 sample_albedo(const rt_dev_scene &sc, uint32_t tex, float u, float v) {
-  rt_texture_desc td = sc.textures[tex];
-  float fu = floorf(u * (float)td.width);
-  float fv = floorf(v * (float)td.height);
-  int w = (int)td.width, h = (int)td.height;
+__device__ __forceinline__ V3 sample_albedo(const rt_dev_scene &sc, uint32_t tex_offset, uint32_t tex_w,
+                                            uint32_t tex_h, float u, float v) {
+  float fu = floorf(u * (float)tex_w);
+  float fv = floorf(v * (float)tex_h);
+  int w = (int)tex_w, h = (int)tex_h;
   fu = fu - floorf(fu / (float)w) * (float)w;
   fv = fv - floorf(fv / (float)h) * (float)h;
   int ix = (fu == fu) ? (int)fu : 0;
   int iy = (fv == fv) ? (int)fv : 0;
   ix = ix < 0 ? 0 : (ix > w - 1 ? w - 1 : ix);
   iy = iy < 0 ? 0 : (iy > h - 1 ? h - 1 : iy);
-  uint32_t px = *reinterpret_cast<const uint32_t *>(sc.texels + td.offset +
-                                                    4u * ((uint32_t)iy * td.width + (uint32_t)ix));
+  uint32_t px = *reinterpret_cast<const uint32_t *>(sc.texels + tex_offset +
+                                                    4u * ((uint32_t)iy * tex_w + (uint32_t)ix));
   return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f,
             (float)((px >> 16) & 255u) / 255.0f);
 }
@@ -512,7 +512,7 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
     p.sample_radiance = p.sample_radiance + p.attenuation * sky;
     return false;
   }
-  const rt_blas_instance &inst = sc.instances[hit.inst];
+  const rt_dev_inst_shade &inst = sc.inst_shade[hit.inst]; // matrices + resolved material: one record
   const float *T = inst.transform, *I = inst.inv_transform;
   // hit point in object space, then to world (Triangle.slang:34, RayTracing.slang:117)
   V3 i0 = ld3(I + 0), i1 = ld3(I + 4), i2 = ld3(I + 8), i3 = ld3(I + 12);
@@ -533,7 +533,8 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
   float uvy = (alpha * sh.uv0[1] + hit.u * sh.uv1[1]) + hit.v * sh.uv2[1];
   V3 pw = mul_cols(ld3(T + 0), ld3(T + 4), ld3(T + 8), ld3(T + 12), p_obj, 1.f);
 
-  uint32_t mtype = inst.material.type, mindex = inst.material.index;
+  const uint32_t mtype = inst.mtype;
+  const float4 mparam = make_float4(inst.param[0], inst.param[1], inst.param[2], inst.param[3]);
   V3 emission = v3(0.f, 0.f, 0.f);
   V3 matt = v3(0.f, 0.f, 0.f);
   V3 out_d = p.d;
@@ -543,16 +544,19 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
     if (near_zero(sd))
       sd = normal;
     out_d = sd;
-    matt = sample_albedo(sc, sc.lamberts[mindex], uvx, uvy);
+    // a 1x1 texture returns its texel for every uv (NaN included): decoded at upload into param
+    matt = (inst.tex_w == 1u && inst.tex_h == 1u)
+               ? v3(mparam.x, mparam.y, mparam.z)
+               : sample_albedo(sc, inst.tex_offset, inst.tex_w, inst.tex_h, uvx, uvy);
     scattered = true;
   } else if (mtype == RT_MATERIAL_METAL) { // Material.slang:39-57
-    float4 m = sc.metals[mindex];
+    const float4 m = mparam;
     V3 reflected = reflect(p.d, normal);
     out_d = reflected + (m.w * rand_unit_vector(rng));
     matt = v3(m.x, m.y, m.z);
     scattered = true;
   } else if (mtype == RT_MATERIAL_DIELECTRIC) { // Material.slang:77-100
-    float refraction_index = sc.dielectrics[mindex];
+    float refraction_index = mparam.x;
     matt = v3(1.f, 1.f, 1.f);
     float ri = front_face ? (1.f / refraction_index) : refraction_index;
     V3 unit = normalize(p.d);
@@ -565,7 +569,7 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
       out_d = rtiow_refract(unit, normal, ri);
     scattered = true;
   } else if (mtype == RT_MATERIAL_EMISSIVE) { // Material.slang:102-108
-    float4 e = sc.emissives[mindex];
+    const float4 e = mparam;
     emission = v3(e.x, e.y, e.z);
   }
   p.sample_radiance = p.sample_radiance + p.attenuation * emission; // :151

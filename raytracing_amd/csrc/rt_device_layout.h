@@ -49,6 +49,21 @@ struct alignas(64) rt_dev_inst { // 64 B: what a TLAS leaf visit needs
   uint32_t pad2;
 };
 
+// What shading one hit needs from its instance, resolved at upload: the reference reads the
+// instance (144 B), then its material table entry, then (Lambert) the texture descriptor, then
+// the texel — four dependent loads (RayTracing.slang:103-157, Material.slang).  Here the material
+// parameters sit next to the matrices, and a 1x1 texture (every constant-colour Lambert,
+// Renderer.cpp:691-703) is decoded once on the host, so shading needs ONE record.
+struct alignas(16) rt_dev_inst_shade {
+  float transform[16];     // column-major, as rt_blas_instance
+  float inv_transform[16];
+  float param[4];          // lambert: constant albedo rgb (if tex_w * tex_h == 1) | metal: albedo rgb, fuzz |
+                           // dielectric: refraction index | emissive: intensity rgb
+  uint32_t mtype;          // rt_material_type
+  uint32_t tex_offset;     // lambert with a real texture: byte offset of its RGBA8 texels, and extent
+  uint32_t tex_w, tex_h;
+};
+
 #define RT_LDS_STACK 24   // stack entries per lane kept in LDS
 #define RT_SPILL_STACK 104 // deeper entries, per-lane scratch
 #define RT_MAX_STACK (RT_LDS_STACK + RT_SPILL_STACK) // 128, as TLAS.slang:17

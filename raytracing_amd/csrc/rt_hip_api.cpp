@@ -67,13 +67,8 @@ struct rt_ctx {
   DevBuf<rt_dev_pair> pairs;
   DevBuf<rt_dev_tri> tris;
   DevBuf<rt_dev_inst> inst_trace;
-  DevBuf<rt_blas_instance> instances;
+  DevBuf<rt_dev_inst_shade> inst_shade; // matrices + resolved material per instance
   DevBuf<rt_triangle_shading> shading;
-  DevBuf<uint32_t> lamberts;
-  DevBuf<float4> metals;
-  DevBuf<float> dielectrics;
-  DevBuf<float4> emissives;
-  DevBuf<rt_texture_desc> textures;
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
@@ -90,6 +85,10 @@ struct rt_ctx {
   rt_scene_desc material_counts{}; // counts only (pointers cleared)
   std::vector<rt_lambert> h_lamberts;
   std::vector<rt_texture_desc> h_textures;
+  std::vector<rt_metal> h_metals;
+  std::vector<rt_dielectric> h_dielectrics;
+  std::vector<rt_emissive> h_emissives;
+  std::vector<uint8_t> h_texels; // 1x1 textures are decoded into the per-instance records
   uint64_t texel_bytes = 0;
   // image
   DevBuf<float> accum_own;
@@ -249,13 +248,41 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
     return rc;
   if ((rc = upload(ctx, ctx->inst_trace, insts.data(), insts.size())) != RT_OK)
     return rc;
-  if ((rc = upload(ctx, ctx->instances, instances, n_inst)) != RT_OK)
+  // per-instance shading records: matrices + the material resolved against the host copies of the
+  // material tables (validated by rt_validate_materials for every instance a TLAS leaf names)
+  std::vector<rt_dev_inst_shade> shade(n_inst);
+  for (uint32_t i = 0; i < n_inst; ++i) {
+    rt_dev_inst_shade &d = shade[i];
+    memset(&d, 0, sizeof d);
+    memcpy(d.transform, instances[i].transform, sizeof d.transform);
+    memcpy(d.inv_transform, instances[i].inv_transform, sizeof d.inv_transform);
+    d.mtype = RT_MATERIAL_NONE;
+    if (i >= f.inst_live.size() || !f.inst_live[i])
+      continue;
+    const rt_material_handle &m = instances[i].material;
+    d.mtype = m.type;
+    if (m.type == RT_MATERIAL_LAMBERT) {
+      const rt_texture_desc &t = ctx->h_textures[ctx->h_lamberts[m.index].index];
+      d.tex_offset = t.offset, d.tex_w = t.width, d.tex_h = t.height;
+      if (t.width == 1 && t.height == 1) { // sample_albedo of a 1x1 texture: the texel, decoded as RGBA8 UNORM
+        const uint8_t *px = ctx->h_texels.data() + t.offset;
+        d.param[0] = (float)px[0] / 255.0f, d.param[1] = (float)px[1] / 255.0f, d.param[2] = (float)px[2] / 255.0f;
+      }
+    } else if (m.type == RT_MATERIAL_METAL) {
+      memcpy(d.param, ctx->h_metals[m.index].albedo_fuzz, sizeof d.param);
+    } else if (m.type == RT_MATERIAL_DIELECTRIC) {
+      d.param[0] = ctx->h_dielectrics[m.index].refraction_index;
+    } else if (m.type == RT_MATERIAL_EMISSIVE) {
+      memcpy(d.param, ctx->h_emissives[m.index].intensity, sizeof d.param);
+    }
+  }
+  if ((rc = upload(ctx, ctx->inst_shade, shade.data(), shade.size())) != RT_OK)
     return rc;
   // the staging vector dies at return: finish the copies first
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->dev.pairs = ctx->pairs.ptr;
   ctx->dev.inst_trace = ctx->inst_trace.ptr;
-  ctx->dev.instances = ctx->instances.ptr;
+  ctx->dev.inst_shade = ctx->inst_shade.ptr;
   ctx->dev.root_ref = root;
   ctx->dev.cache_pairs = cached;
   ctx->pair_count = (uint32_t)all.size();
@@ -326,13 +353,8 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->pairs.release();
   ctx->tris.release();
   ctx->inst_trace.release();
-  ctx->instances.release();
+  ctx->inst_shade.release();
   ctx->shading.release();
-  ctx->lamberts.release();
-  ctx->metals.release();
-  ctx->dielectrics.release();
-  ctx->emissives.release();
-  ctx->textures.release();
   ctx->texels.release();
   ctx->counter.release();
   ctx->queue.release();
@@ -370,35 +392,25 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *sc) {
     return rc;
   if ((rc = upload(ctx, ctx->shading, sc->tri_shading, sc->tri_capacity)) != RT_OK)
     return rc;
-  if ((rc = upload(ctx, ctx->lamberts, sc->lamberts, sc->lambert_count)) != RT_OK)
-    return rc;
-  if ((rc = upload(ctx, ctx->metals, sc->metals, sc->metal_count)) != RT_OK)
-    return rc;
-  if ((rc = upload(ctx, ctx->dielectrics, sc->dielectrics, sc->dielectric_count)) != RT_OK)
-    return rc;
-  if ((rc = upload(ctx, ctx->emissives, sc->emissives, sc->emissive_count)) != RT_OK)
-    return rc;
-  if ((rc = upload(ctx, ctx->textures, sc->textures, sc->texture_count)) != RT_OK)
-    return rc;
   if ((rc = upload(ctx, ctx->texels, sc->texels, (size_t)sc->texel_bytes)) != RT_OK)
     return rc;
   ctx->dev.tris = ctx->tris.ptr;
   ctx->dev.shading = ctx->shading.ptr;
-  ctx->dev.lamberts = ctx->lamberts.ptr;
-  ctx->dev.metals = ctx->metals.ptr;
-  ctx->dev.dielectrics = ctx->dielectrics.ptr;
-  ctx->dev.emissives = ctx->emissives.ptr;
-  ctx->dev.textures = ctx->textures.ptr;
   ctx->dev.texels = ctx->texels.ptr;
-  if ((rc = upload_pairs_and_instances(ctx, sc->instances, sc->instance_count)) != RT_OK)
-    return rc;
-  // keep what rt_update_instances must re-validate against
+  // host copies of the material tables: the per-instance shading records are resolved against them
+  // (now and in rt_update_instances), and rt_update_instances re-validates against their counts
   ctx->material_counts = *sc;
   ctx->h_lamberts.assign(sc->lamberts, sc->lamberts + sc->lambert_count);
   ctx->h_textures.assign(sc->textures, sc->textures + sc->texture_count);
+  ctx->h_metals.assign(sc->metals, sc->metals + sc->metal_count);
+  ctx->h_dielectrics.assign(sc->dielectrics, sc->dielectrics + sc->dielectric_count);
+  ctx->h_emissives.assign(sc->emissives, sc->emissives + sc->emissive_count);
+  ctx->h_texels.assign(sc->texels, sc->texels + sc->texel_bytes);
   ctx->material_counts.lamberts = ctx->h_lamberts.data();
   ctx->material_counts.textures = ctx->h_textures.data();
   ctx->texel_bytes = sc->texel_bytes;
+  if ((rc = upload_pairs_and_instances(ctx, sc->instances, sc->instance_count)) != RT_OK)
+    return rc;
   ctx->flat.tris.clear();
   ctx->flat.tris.shrink_to_fit(); // resident in HBM now
   ctx->have_scene = true;
@@ -633,7 +645,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
   out->stack_depth_needed = ctx->flat.stack_needed;
   out->device_bytes = ctx->pairs.count * sizeof(rt_dev_pair) + ctx->tris.count * sizeof(rt_dev_tri) +
                       ctx->inst_trace.count * sizeof(rt_dev_inst) +
-                      ctx->instances.count * sizeof(rt_blas_instance) +
+                      ctx->inst_shade.count * sizeof(rt_dev_inst_shade) +
                       ctx->shading.count * sizeof(rt_triangle_shading) + ctx->texels.count;
   return RT_OK;
 }

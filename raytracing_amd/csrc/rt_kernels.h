@@ -18,14 +18,9 @@ struct rt_dev_scene {
   const rt_dev_pair *pairs;          // TLAS + BLAS interior records
   const rt_dev_tri *tris;            // leaf-ordered triangles
   const rt_dev_inst *inst_trace;     // per instance: inv_transform columns + BLAS root
-  const rt_blas_instance *instances; // reference layout, read once per shaded hit
+  const rt_dev_inst_shade *inst_shade; // per instance: matrices + resolved material, read once per shaded hit
   const rt_triangle_shading *shading; // reference layout, indexed by triangle id
-  const uint32_t *lamberts;
-  const float4 *metals;
-  const float *dielectrics;
-  const float4 *emissives;
-  const rt_texture_desc *textures;
-  const uint8_t *texels;
+  const uint8_t *texels;              // RGBA8 texels of the non-constant Lambert textures
   uint32_t root_ref; // TLAS root reference (RT_REF_NONE for an empty scene)
   uint32_t cache_pairs; // pairs[0, cache_pairs) are the breadth-first top of the scene
   uint32_t flags;       // RT_SCENE_*
