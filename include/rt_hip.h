@@ -111,6 +111,17 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
 int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t count, float *q_fast,
                       float *q_ieee);
 
+/* replaces the clustering loop of TLAS::build, src/TLAS.cpp:38-58 with find_best_match :61-80 (called from
+ * Renderer::build_tlas, src/Renderer.cpp:994-1015, whenever an instance is added, moved or removed).
+ * `leaves` are the n leaf nodes of TLAS.cpp:15-36 (world boxes, blas_instance_idx, left_right = 0) in list order;
+ * `out_nodes` receives 2n nodes laid out as the reference lays them out: root copy at 0, leaves at 1..n, merged
+ * nodes behind them; `*out_node_count` = 2n - 1 (the value TLAS::build returns).  The loop is sequential, so it
+ * runs in one 512-lane workgroup with the live list in registers and LDS; n is limited to RT_TLAS_GPU_MAX_LEAVES.  The result
+ * is bit-equal to the host builder (rth_build_tlas).  `kernel_ms` (optional) receives the kernel time. */
+#define RT_TLAS_GPU_MAX_LEAVES 4096u
+int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                          uint32_t *out_node_count, float *kernel_ms);
+
 const char *rt_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only machine; never fails) */
 int rt_device_count(void);

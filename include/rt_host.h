@@ -37,7 +37,8 @@ enum rth_option {
   RTH_FRAME_OFFSET = 5,
   RTH_KERNEL_VARIANT = 6,
   RTH_ROW_BEGIN = 7, /* multi-GPU row sharding: render rows [begin, end) only; 0,0 = all */
-  RTH_ROW_END = 8
+  RTH_ROW_END = 8,
+  RTH_TLAS_GPU_MIN_INSTANCES = 9 /* TLAS clustering on the GPU from this many instances on; 0 = host only */
 };
 
 /* Renderer::init / shutdown / resize / render, src/Renderer.cpp:215-652.
@@ -125,6 +126,13 @@ uint32_t rth_build_blas(rt_bvh_node *nodes, const rt_triangle_geom *tris, const 
 uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instances,
                         const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                         const rt_bvh_node *bvh_nodes);
+/* the two halves of rth_build_tlas: leaf boxes (TLAS.cpp:15-36) and the clustering loop (TLAS.cpp:38-58) over
+ * nodes[1..n]; the loop's GPU counterpart is rt_build_tlas_cluster (rt_hip.h) */
+void rth_tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids,
+                     uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes);
+uint32_t rth_tlas_cluster(rt_tlas_node *nodes, uint32_t n);
+/* 1 if the renderer's last TLAS build ran its clustering loop on the GPU; *kernel_ms (optional) = its kernel time */
+int rth_last_tlas_build(rth_renderer *r, float *kernel_ms);
 void rth_mat4_inverse(const float *m16, float *out16);
 
 #ifdef __cplusplus

@@ -19,7 +19,8 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_last_error_string",
+    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
+    "rt_last_error_string",
     "rt_device_count",
 ]
 
@@ -76,6 +77,7 @@ def lib():
     L.rt_reset_stats.argtypes = [vp]
     L.rt_set_kernel_variant.argtypes = [vp, u32]
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -129,6 +131,16 @@ class HipContext:
         q_ieee = np.empty_like(n)
         _check(lib().rt_debug_fast_div(self._h, T.ptr(n), T.ptr(d), n.size, T.ptr(q_fast), T.ptr(q_ieee)))
         return q_fast, q_ieee
+
+    def build_tlas_cluster(self, leaves):
+        """TLAS::build's clustering loop (TLAS.cpp:38-58) on the GPU: (nodes[2n], node_count, kernel_ms)."""
+        import numpy as np
+        leaves = np.ascontiguousarray(leaves, T.tlas_node_dtype)
+        out = np.zeros(2 * max(leaves.size, 1), T.tlas_node_dtype)
+        count, ms = C.c_uint32(0), C.c_float(0)
+        _check(lib().rt_build_tlas_cluster(self._h, T.ptr(leaves), leaves.size, T.ptr(out), C.byref(count),
+                                           C.byref(ms)))
+        return out, int(count.value), float(ms.value)
 
     def set_camera(self, cam):
         _check(lib().rt_set_camera(self._h, C.byref(cam)))

@@ -225,12 +225,8 @@ int best_match(const rt_tlas_node *nodes, const std::vector<int> &list, int coun
 }
 } // namespace
 
-uint32_t build_tlas(rt_tlas_node *out, const rt_blas_instance *instances, const uint32_t *instance_ids,
-                    uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes) {
-  if (n == 0)
-    return 0;
-  uint32_t count = 1;
-  std::vector<int> live(n);
+void tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids, uint32_t n,
+                 const rt_blas *blas, const rt_bvh_node *bvh_nodes) {
   for (uint32_t k = 0; k < n; ++k) { // TLAS.cpp:15-36
     const uint32_t id = instance_ids[k];
     const rt_bvh_node &root = bvh_nodes[blas[instances[id].blas_id].bvh_nodes_offset];
@@ -242,13 +238,21 @@ uint32_t build_tlas(rt_tlas_node *out, const rt_blas_instance *instances, const 
       vec4 p = to_world * vec4(corner, 1.0f);
       world.grow(vec3(p.x, p.y, p.z));
     }
-    live[k] = (int)count;
-    rt_tlas_node &leaf = out[count++];
+    rt_tlas_node &leaf = leaves[k];
     world.lo.store(leaf.aabb_min);
     world.hi.store(leaf.aabb_max);
     leaf.blas_instance_idx = id;
     leaf.left_right = 0;
   }
+}
+
+uint32_t tlas_cluster(rt_tlas_node *out, uint32_t n) {
+  if (n == 0)
+    return 0;
+  uint32_t count = n + 1;
+  std::vector<int> live(n);
+  for (uint32_t k = 0; k < n; ++k)
+    live[k] = (int)(k + 1);
   int remaining = (int)n;
   int a = 0, b = best_match(out, live, remaining, a); // TLAS.cpp:39-55
   while (remaining > 1) {
@@ -270,6 +274,14 @@ uint32_t build_tlas(rt_tlas_node *out, const rt_blas_instance *instances, const 
   }
   out[0] = out[live[a]]; // TLAS.cpp:57
   return count - 1;
+}
+
+uint32_t build_tlas(rt_tlas_node *out, const rt_blas_instance *instances, const uint32_t *instance_ids,
+                    uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes) {
+  if (n == 0)
+    return 0;
+  tlas_leaves(out + 1, instances, instance_ids, n, blas, bvh_nodes);
+  return tlas_cluster(out, n);
 }
 
 } // namespace rta

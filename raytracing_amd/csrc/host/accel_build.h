@@ -24,6 +24,12 @@ void refit_blas(rt_bvh_node *nodes, uint32_t nodes_count, const rt_triangle_geom
 
 // tlas_nodes: room for 2*n entries.  instance_ids gives the leaf order
 // (leaf k+1 <- instance_ids[k]).  Returns the node count (2n-1; 0 for n == 0).
+// The two halves of build_tlas: the leaf boxes (TLAS.cpp:15-36; leaves[k] <- instance_ids[k]) and the clustering
+// loop (TLAS.cpp:38-58) over nodes[1..n] already holding those leaves.  The second half has a GPU counterpart,
+// rt_build_tlas_cluster (include/rt_hip.h), which rta::Renderer uses for large instance counts.
+void tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids, uint32_t n,
+                 const rt_blas *blas, const rt_bvh_node *bvh_nodes);
+uint32_t tlas_cluster(rt_tlas_node *nodes, uint32_t n);
 uint32_t build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instances,
                     const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                     const rt_bvh_node *bvh_nodes);

@@ -104,6 +104,9 @@ int rth_set_option(rth_renderer *r, int option, uint32_t value) {
   case RTH_ROW_END:
     r->r.row_end = value;
     break;
+  case RTH_TLAS_GPU_MIN_INSTANCES:
+    r->r.tlas_gpu_min_instances = value;
+    return RT_OK; // the nodes are the same either way: the running mean stays valid
   case RTH_KERNEL_VARIANT:
     if (!r->r.context())
       return RT_ERR_NO_DEVICE;
@@ -285,6 +288,18 @@ uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instan
                         const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                         const rt_bvh_node *bvh_nodes) {
   return rta::build_tlas(tlas_nodes, instances, instance_ids, n, blas, bvh_nodes);
+}
+void rth_tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids,
+                     uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes) {
+  rta::tlas_leaves(leaves, instances, instance_ids, n, blas, bvh_nodes);
+}
+uint32_t rth_tlas_cluster(rt_tlas_node *nodes, uint32_t n) { return rta::tlas_cluster(nodes, n); }
+int rth_last_tlas_build(rth_renderer *r, float *kernel_ms) {
+  if (!r)
+    return 0;
+  if (kernel_ms)
+    *kernel_ms = r->r.last_tlas_on_gpu ? r->r.last_tlas_kernel_ms : 0.f;
+  return r->r.last_tlas_on_gpu ? 1 : 0;
 }
 void rth_mat4_inverse(const float *m16, float *out16) { rta::inverse(rta::mat4(m16)).store(out16); }
 

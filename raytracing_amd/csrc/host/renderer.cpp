@@ -385,9 +385,28 @@ void Renderer::remove_blas_instance(uint32_t id) {
 // ---- TLAS + publication (Renderer.cpp:994-1015) -----------------------------
 void Renderer::build_tlas() {
   std::vector<uint32_t> ids(blas_instance_ids_.begin(), blas_instance_ids_.end()); // ascending
+  const uint32_t n = (uint32_t)ids.size();
   tlas_nodes_.assign(std::max<size_t>(ids.size() * 2, 1), rt_tlas_node{});
-  tlas_node_count_ = rta::build_tlas(tlas_nodes_.data(), blas_instances_.data(), ids.data(),
-                                (uint32_t)ids.size(), blases_.data(), bvh_nodes_.data());
+  last_tlas_on_gpu = false;
+  if (n) {
+    rta::tlas_leaves(tlas_nodes_.data() + 1, blas_instances_.data(), ids.data(), n, blases_.data(), bvh_nodes_.data());
+    // The clustering loop is O(n^2)..O(n^3) and sequential; from about 1500 instances on, one GPU workgroup with
+    // the live list in registers finishes it sooner than a host core (same nodes, bit for bit).
+    if (ctx_ && tlas_gpu_min_instances && n >= tlas_gpu_min_instances && n <= RT_TLAS_GPU_MAX_LEAVES) {
+      std::vector<rt_tlas_node> leaves(tlas_nodes_.begin() + 1, tlas_nodes_.begin() + 1 + n);
+      uint32_t count = 0;
+      if (rt_build_tlas_cluster(ctx_, leaves.data(), n, tlas_nodes_.data(), &count, &last_tlas_kernel_ms) == RT_OK) {
+        tlas_node_count_ = count;
+        last_tlas_on_gpu = true;
+      } else {
+        warn(std::string("build_tlas: GPU clustering refused (") + rt_last_error_string() + "), building on the host");
+      }
+    }
+    if (!last_tlas_on_gpu)
+      tlas_node_count_ = rta::tlas_cluster(tlas_nodes_.data(), n);
+  } else {
+    tlas_node_count_ = 0;
+  }
   rebuild_tlas_ = false;
   instances_dirty_ = true;
   frame_index = 0;

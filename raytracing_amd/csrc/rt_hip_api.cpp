@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <math.h>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -713,6 +714,57 @@ int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t coun
   HIP_TRY(hipMemcpyAsync(q_fast, bf.ptr, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(q_ieee, bi.ptr, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                          uint32_t *out_node_count, float *kernel_ms) {
+  if (!ctx || !leaves || !out_nodes || !out_node_count || n == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: bad argument");
+  if (n > RT_TLAS_GPU_MAX_LEAVES)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: more than RT_TLAS_GPU_MAX_LEAVES leaves");
+  for (uint32_t k = 0; k < n; ++k) {
+    if (leaves[k].left_right != 0)
+      return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: input node is not a leaf");
+    for (int c = 0; c < 3; ++c) // the kernel's scan relies on finite boxes (rt_tlas_build.hip)
+      if (!std::isfinite(leaves[k].aabb_min[c]) || !std::isfinite(leaves[k].aabb_max[c]))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: instance boxes are not finite");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  struct ScopedN : DevBuf<rt_tlas_node> {
+    ~ScopedN() { release(); }
+  } d_leaves, d_out;
+  struct ScopedC : DevBuf<uint32_t> {
+    ~ScopedC() { release(); }
+  } d_count;
+  HIP_TRY(d_leaves.reserve(n));
+  HIP_TRY(d_out.reserve(2 * (size_t)n));
+  HIP_TRY(d_count.reserve(1));
+  HIP_TRY(hipMemcpyAsync(d_leaves.ptr, leaves, (size_t)n * sizeof(rt_tlas_node), hipMemcpyHostToDevice, ctx->stream));
+  struct ScopedEvents {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~ScopedEvents() {
+      if (a)
+        (void)hipEventDestroy(a);
+      if (b)
+        (void)hipEventDestroy(b);
+    }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a));
+  HIP_TRY(hipEventCreate(&ev.b));
+  HIP_TRY(hipEventRecord(ev.a, ctx->stream));
+  HIP_TRY(rt_launch_tlas_cluster(d_leaves.ptr, n, d_out.ptr, d_count.ptr, ctx->stream));
+  HIP_TRY(hipEventRecord(ev.b, ctx->stream));
+  uint32_t count = 0;
+  HIP_TRY(hipMemcpyAsync(&count, d_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out_nodes, d_out.ptr, 2 * (size_t)n * sizeof(rt_tlas_node), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (kernel_ms)
+    HIP_TRY(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
+  if (count == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: instance boxes are not finite");
+  *out_node_count = count;
   return RT_OK;
 }
 

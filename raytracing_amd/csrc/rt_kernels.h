@@ -44,6 +44,10 @@ hipError_t rt_launch_render_v7(uint32_t variant, const rt_dev_scene &sc, const r
 hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
                                 unsigned long long *d_out, hipStream_t stream);
 
+// rt_tlas_build.hip: TLAS::build's clustering loop (src/TLAS.cpp:38-58) in one workgroup; out has 2n nodes
+hipError_t rt_launch_tlas_cluster(const rt_tlas_node *d_leaves, uint32_t n, rt_tlas_node *d_out,
+                                  uint32_t *d_out_count, hipStream_t stream);
+
 hipError_t rt_launch_debug_fast_div(const float *d_n, const float *d_d, uint64_t count, float *d_fast,
                                     float *d_ieee, hipStream_t stream);
 

@@ -18,6 +18,7 @@ HOST_LIB_PATH = os.path.join(_PKG, "librt_host.so")
 OPT_SAMPLES_PER_PIXEL, OPT_MAX_DEPTH, OPT_RNG_MODE, OPT_AABB_MODE = 0, 1, 2, 3
 OPT_FRAME_STRIDE, OPT_FRAME_OFFSET, OPT_KERNEL_VARIANT = 4, 5, 6
 OPT_ROW_BEGIN, OPT_ROW_END = 7, 8
+OPT_TLAS_GPU_MIN_INSTANCES = 9
 PLANE, CUBE, SPHERE = 0, 1, 2
 
 HOST_SYMBOLS = [
@@ -30,7 +31,8 @@ HOST_SYMBOLS = [
     "rth_camera_uniforms", "rth_read_image", "rth_wait", "rth_context", "rth_last_error", "rth_trs",
     "rth_make_primitive", "rth_make_dragon", "rth_load_obj", "rth_load_scene_file", "rth_mesh_free", "rth_mesh_vertex_count",
     "rth_mesh_index_count", "rth_mesh_positions", "rth_mesh_normals", "rth_mesh_uvs",
-    "rth_mesh_indices", "rth_build_blas", "rth_build_tlas", "rth_mat4_inverse",
+    "rth_mesh_indices", "rth_build_blas", "rth_build_tlas", "rth_tlas_leaves", "rth_tlas_cluster",
+    "rth_last_tlas_build", "rth_mat4_inverse",
 ]
 
 
@@ -99,6 +101,9 @@ def lib():
         getattr(L, n).argtypes = [vp]; getattr(L, n).restype = vp
     L.rth_build_blas.argtypes = [vp, vp, vp, vp, u32, u32]; L.rth_build_blas.restype = u32
     L.rth_build_tlas.argtypes = [vp, vp, vp, u32, vp, vp]; L.rth_build_tlas.restype = u32
+    L.rth_tlas_leaves.argtypes = [vp, vp, vp, u32, vp, vp]; L.rth_tlas_leaves.restype = None
+    L.rth_tlas_cluster.argtypes = [vp, u32]; L.rth_tlas_cluster.restype = u32
+    L.rth_last_tlas_build.argtypes = [vp, C.POINTER(C.c_float)]; L.rth_last_tlas_build.restype = C.c_int
     L.rth_mat4_inverse.argtypes = [vp, vp]; L.rth_mat4_inverse.restype = None
     _LIB = L
     return L
@@ -312,6 +317,12 @@ class Renderer:
 
     def set_option(self, option, value):
         self._ok(lib().rth_set_option(self._h, option, value))
+
+    def last_tlas_build(self):
+        """(ran_on_gpu, kernel_ms) of the last TLAS build (Renderer.cpp:994-1015)."""
+        ms = C.c_float(0)
+        on_gpu = lib().rth_last_tlas_build(self._h, C.byref(ms))
+        return bool(on_gpu), float(ms.value)
 
     def reset_accumulation(self):
         lib().rth_reset_accumulation(self._h)

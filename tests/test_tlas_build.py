@@ -1,0 +1,159 @@
+"""TLAS::build's clustering loop (src/TLAS.cpp:38-58, find_best_match :61-80).
+
+CPU: the host builder's two halves (rth_tlas_leaves + rth_tlas_cluster) reproduce the oracle's orc_build_tlas.
+GPU: rt_build_tlas_cluster (one workgroup, live list in LDS) returns the same nodes bit for bit, including ties
+(grid-aligned boxes), degenerate boxes, the maximum size, and through rta::Renderer's automatic switch-over.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_amd import _ffi
+from raytracing_amd import _types as T
+from raytracing_amd import renderer as R
+from . import _oracle as O
+from . import _scenes as S
+
+
+def _same_struct(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    assert a.tobytes() == b.tobytes()
+
+
+def _leaves(n, seed, kind="random"):
+    rng = np.random.default_rng(seed)
+    lv = np.zeros(n, T.tlas_node_dtype)
+    if kind == "random":
+        c = rng.uniform(-50, 50, (n, 3)).astype(np.float32)
+        e = rng.uniform(0.1, 3.0, (n, 3)).astype(np.float32)
+    elif kind == "grid":  # equal boxes on an integer grid: many exactly equal union areas -> first index must win
+        side = int(np.ceil(n ** (1 / 3)))
+        g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+        c = (g * 2).astype(np.float32)
+        e = np.full((n, 3), 0.5, np.float32)
+    elif kind == "flat":  # zero-extent boxes (area 0 unions) and duplicates
+        c = rng.integers(-3, 4, (n, 3)).astype(np.float32)
+        e = np.zeros((n, 3), np.float32)
+    else:
+        raise ValueError(kind)
+    lv["aabb_min"], lv["aabb_max"] = c - e, c + e
+    lv["blas_instance_idx"] = rng.permutation(n).astype(np.uint32)
+    return lv
+
+
+def _host_cluster(leaves):
+    n = leaves.size
+    nodes = np.zeros(2 * max(n, 1), T.tlas_node_dtype)
+    nodes[1:1 + n] = leaves
+    cnt = R.lib().rth_tlas_cluster(T.ptr(nodes), n)
+    return nodes, cnt
+
+
+def test_host_halves_equal_oracle_builder():
+    o = S.mixed_scene(n_side=6, seed=9)  # 37 instances
+    so = o.build()
+    n = len(o.instances)
+    ids = np.arange(n, dtype=np.uint32)
+    lv = np.zeros(n, T.tlas_node_dtype)
+    R.lib().rth_tlas_leaves(T.ptr(lv), T.ptr(o.instances), T.ptr(ids), n, T.ptr(o.blas), T.ptr(o.nodes))
+    _same_struct(lv, so.tlas_nodes[1:1 + n])
+    nodes, cnt = _host_cluster(lv)
+    assert cnt == so.tlas_node_count == 2 * n - 1
+    _same_struct(nodes[:cnt], so.tlas_nodes[:cnt])
+
+
+@pytest.mark.parametrize("kind,n", [("random", 300), ("grid", 343), ("flat", 200)])
+def test_host_cluster_is_a_valid_tree(kind, n):
+    nodes, cnt = _host_cluster(_leaves(n, 3, kind))
+    assert cnt == 2 * n - 1
+    seen = np.zeros(cnt + 1, np.int32)
+    stack = [0]
+    leaves = []
+    while stack:
+        k = stack.pop()
+        lr = int(nodes[k]["left_right"])
+        if lr == 0:
+            leaves.append(int(nodes[k]["blas_instance_idx"]))
+            continue
+        for ch in (lr & 0xFFFF, lr >> 16):
+            assert 1 <= ch <= cnt and (nodes[ch]["aabb_min"] >= nodes[k]["aabb_min"]).all()
+            assert (nodes[ch]["aabb_max"] <= nodes[k]["aabb_max"]).all()
+            seen[ch] += 1
+            stack.append(ch)
+    assert sorted(leaves) == list(range(n)) and seen.max() == 1
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,seed", [("random", 1, 0), ("random", 2, 1), ("random", 3, 2), ("random", 64, 3),
+                                         ("random", 257, 4), ("random", 1000, 5), ("random", 2025, 6),
+                                         ("grid", 343, 7), ("grid", 1331, 8), ("flat", 200, 9), ("flat", 1500, 10),
+                                         ("random", 4096, 11)])
+def test_gpu_cluster_equals_host_builder(ctx, kind, n, seed):
+    lv = _leaves(n, seed, kind)
+    want, cnt = _host_cluster(lv)
+    got, gcnt, ms = ctx.build_tlas_cluster(lv)
+    assert gcnt == cnt == 2 * n - 1 and ms > 0
+    _same_struct(got[:cnt], want[:cnt])
+
+
+@pytest.mark.gpu
+def test_gpu_cluster_rejects_bad_input(ctx):
+    lv = _leaves(8, 0)
+    with pytest.raises(_ffi.RtError):
+        ctx.build_tlas_cluster(_leaves(4097, 0))
+    bad = lv.copy()
+    bad["left_right"][3] = 5  # not a leaf
+    with pytest.raises(_ffi.RtError):
+        ctx.build_tlas_cluster(bad)
+    inf = lv.copy()
+    inf["aabb_max"][:] = np.inf  # every union area is inf: the reference's loop would index with -1
+    with pytest.raises(_ffi.RtError):
+        ctx.build_tlas_cluster(inf)
+    out = np.zeros(16, T.tlas_node_dtype)
+    cnt = C.c_uint32(0)
+    assert _ffi.lib().rt_build_tlas_cluster(ctx._h, None, 8, T.ptr(out), C.byref(cnt), None) != 0
+    assert _ffi.lib().rt_build_tlas_cluster(ctx._h, T.ptr(lv), 0, T.ptr(out), C.byref(cnt), None) != 0
+
+
+@pytest.mark.gpu
+def test_renderer_switches_to_gpu_cluster_and_publishes_the_same_tlas():
+    """rta::Renderer::build_tlas (Renderer.cpp:994-1015): above the threshold the loop runs on the GPU; the
+    published nodes equal the host-built ones, also after an instance moved and after one was removed."""
+    rng = np.random.default_rng(5)
+
+    def populate(r):
+        mat = r.add_lambert_material((0.5, 0.5, 0.5))
+        ids = []
+        for k in range(400):
+            p = rng.uniform(-20, 20, 3)
+            ids.append(r.add_blas_instance(r.cube_blas_index if k % 2 else r.sphere_blas_index,
+                                           R.trs(tuple(p), float(rng.uniform(0, 3)), (0, 1, 0), (1, 1, 1)), mat))
+        return ids
+
+    state = rng.bit_generator.state
+    rg = R.Renderer(64, 64, device=0)
+    rg.set_option(R.OPT_TLAS_GPU_MIN_INSTANCES, 256)  # default 1536: the measured break-even
+    ids_g = populate(rg)
+    rng.bit_generator.state = state
+    rh = R.Renderer(64, 64, device=0)
+    rh.set_option(R.OPT_TLAS_GPU_MIN_INSTANCES, 0)
+    ids_h = populate(rh)
+    for step in range(3):
+        if step == 1:
+            m = R.trs((1.0, 2.0, 3.0), 0.7, (0, 1, 0), (2, 2, 2))
+            rg.set_blas_instance_transform(ids_g[17], m), rh.set_blas_instance_transform(ids_h[17], m)
+        if step == 2:
+            rg.remove_blas_instance(ids_g[250]), rh.remove_blas_instance(ids_h[250])
+        sg, sh = rg.scene_arrays(), rh.scene_arrays()
+        assert rg.last_tlas_build()[0] and not rh.last_tlas_build()[0]
+        assert sg.tlas_node_count == sh.tlas_node_count == 2 * (400 - (step == 2)) - 1
+        _same_struct(sg.tlas_nodes[:sg.tlas_node_count], sh.tlas_nodes[:sh.tlas_node_count])
