@@ -55,6 +55,13 @@ void rth_reset_accumulation(rth_renderer *r); /* frame_index = 0 */
 rt_material_handle rth_add_lambert_material(rth_renderer *r, const float *albedo_rgb);
 rt_material_handle rth_add_lambert_texture(rth_renderer *r, int32_t width, int32_t height,
                                            const uint8_t *rgba8);
+/* add_lambert_material(std::string_view file_path), src/Renderer.cpp:705-716: PNG or binary PNM, decoded to RGBA8
+ * as stbi_load(.., 4) returns it; type RT_MATERIAL_NONE if the file cannot be decoded (see rth_last_error) */
+rt_material_handle rth_add_lambert_image(rth_renderer *r, const char *file_path);
+/* the decoder alone: fills *width / *height and, if rgba8 != NULL and capacity >= w*h*4, the pixels; returns 0 or
+ * -1 with a message in err */
+int rth_decode_image(const char *file_path, uint32_t *width, uint32_t *height, uint8_t *rgba8, uint64_t capacity,
+                     char *err, size_t err_len);
 rt_material_handle rth_add_metal_material(rth_renderer *r, const float *albedo_rgb, float fuzz);
 rt_material_handle rth_add_dielectric_material(rth_renderer *r, float refractive_index);
 rt_material_handle rth_add_emissive_material(rth_renderer *r, const float *intensity_rgb);

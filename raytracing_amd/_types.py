@@ -77,7 +77,7 @@ class RenderParams(C.Structure):  # src/Renderer.cpp:48-62
                 ("row_end", u32), ("reserved", u32 * 2)]
 
 
-MATERIAL_LAMBERT, MATERIAL_METAL, MATERIAL_DIELECTRIC, MATERIAL_EMISSIVE = 0, 1, 2, 3
+MATERIAL_LAMBERT, MATERIAL_METAL, MATERIAL_DIELECTRIC, MATERIAL_EMISSIVE, MATERIAL_NONE = 0, 1, 2, 3, 4
 RNG_WANG, RNG_PCG = 0, 1
 AABB_DIV, AABB_RCP = 0, 1
 INVALID_ID = 0xFFFFFFFF

@@ -7,6 +7,7 @@
 #include "../../../include/rt_host.h"
 #include "accel_build.h"
 #include "meshes.h"
+#include "image_decode.h"
 #include "renderer.h"
 #include "scene_file.h"
 
@@ -129,6 +130,25 @@ rt_material_handle rth_add_lambert_material(rth_renderer *r, const float *rgb) {
 }
 rt_material_handle rth_add_lambert_texture(rth_renderer *r, int32_t w, int32_t h, const uint8_t *px) {
   return r ? r->r.add_lambert_material(w, h, px) : kNoMaterial;
+}
+rt_material_handle rth_add_lambert_image(rth_renderer *r, const char *file_path) {
+  return r && file_path ? r->r.add_lambert_material(std::string(file_path)) : kNoMaterial;
+}
+int rth_decode_image(const char *file_path, uint32_t *width, uint32_t *height, uint8_t *rgba8, uint64_t capacity,
+                     char *err, size_t err_len) {
+  rta::Image img;
+  std::string e;
+  if (!file_path || !width || !height) {
+    e = "rth_decode_image: NULL argument";
+  } else if (rta::load_image_rgba8(file_path, img, e)) {
+    *width = img.width, *height = img.height;
+    if (rgba8 && capacity >= img.rgba.size())
+      memcpy(rgba8, img.rgba.data(), img.rgba.size());
+    return 0;
+  }
+  if (err && err_len)
+    snprintf(err, err_len, "%s", e.c_str());
+  return -1;
 }
 rt_material_handle rth_add_metal_material(rth_renderer *r, const float *rgb, float fuzz) {
   return r && rgb ? r->r.add_metal_material(rta::vec3(rgb), fuzz) : kNoMaterial;

@@ -1,0 +1,22 @@
+// image_decode.h — image files to RGBA8 for Renderer::add_lambert_material(path) (src/Renderer.cpp:705-716,
+// which calls stbi_load(path, &w, &h, &comp, 4)).  PNG and binary PNM; see image_decode.cpp.
+#ifndef RTA_IMAGE_DECODE_H
+#define RTA_IMAGE_DECODE_H
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace rta {
+
+struct Image {
+  uint32_t width = 0, height = 0;
+  std::vector<uint8_t> rgba; // width * height * 4, rows top to bottom (no vertical flip, Renderer.cpp:707)
+};
+
+bool decode_image_rgba8(const std::vector<uint8_t> &file_bytes, Image &out, std::string &err);
+bool load_image_rgba8(const std::string &path, Image &out, std::string &err);
+
+} // namespace rta
+#endif

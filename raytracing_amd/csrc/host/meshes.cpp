@@ -215,7 +215,38 @@ void load_mtl(const std::string &path, std::vector<ObjMaterial> &mats) {
       ss >> mats.back().kd[0] >> mats.back().kd[1] >> mats.back().kd[2];
       mats.back().has_kd = true;
     } else if (!mats.empty() && key == "map_Kd") {
-      ss >> mats.back().map_kd;
+      // tinyobj's ParseTextureNameAndOption: options (with their values) are skipped, the rest is the file name
+      std::string tok, name;
+      while (ss >> tok) {
+        int skip = -1;
+        if (tok == "-blendu" || tok == "-blendv" || tok == "-clamp" || tok == "-boost" || tok == "-bm" ||
+            tok == "-imfchan" || tok == "-type" || tok == "-texres" || tok == "-colorspace")
+          skip = 1;
+        else if (tok == "-mm")
+          skip = 2;
+        else if (tok == "-o" || tok == "-s" || tok == "-t")
+          skip = 3; // u [v [w]]: tinyobj reads up to three numbers
+        if (skip < 0) {
+          name += (name.empty() ? "" : " ") + tok;
+          continue;
+        }
+        for (int k = 0; k < skip; ++k) {
+          std::streampos at = ss.tellg();
+          std::string val;
+          if (!(ss >> val))
+            break;
+          if ((tok == "-o" || tok == "-s" || tok == "-t") && k > 0) { // optional v, w: only numbers are consumed
+            char *endp = nullptr;
+            strtod(val.c_str(), &endp);
+            if (endp == val.c_str() || *endp) {
+              ss.clear();
+              ss.seekg(at);
+              break;
+            }
+          }
+        }
+      }
+      mats.back().map_kd = name;
     }
   }
 }

@@ -1,6 +1,8 @@
 // renderer.cpp — see renderer.h.
 #include "renderer.h"
 
+#include "image_decode.h"
+
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -171,6 +173,16 @@ rt_material_handle Renderer::add_lambert_material(vec3 albedo) {
   uint8_t px[4] = {(uint8_t)(clamp01(albedo.x) * 255.f), (uint8_t)(clamp01(albedo.y) * 255.f),
                    (uint8_t)(clamp01(albedo.z) * 255.f), 255}; // :696-699
   return add_lambert_material(1, 1, px);
+}
+
+rt_material_handle Renderer::add_lambert_material(const std::string &file_path) {
+  Image img;
+  std::string err;
+  if (!load_image_rgba8(file_path, img, err)) { // HASSERT_MSGS(raw_bdata, "Failed to load image"), :710
+    warn("add_lambert_material: failed to load image: " + err);
+    return {0, RT_MATERIAL_NONE};
+  }
+  return add_lambert_material((int32_t)img.width, (int32_t)img.height, img.rgba.data());
 }
 
 rt_material_handle Renderer::add_metal_material(vec3 albedo, float fuzz) {

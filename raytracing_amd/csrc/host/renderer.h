@@ -70,6 +70,9 @@ public:
 
   rt_material_handle add_lambert_material(vec3 albedo);
   rt_material_handle add_lambert_material(int32_t width, int32_t height, const uint8_t *pixels);
+  // image file (PNG, binary PNM) decoded to RGBA8 like stbi_load(path, .., 4), Renderer.cpp:705-716; a file that
+  // cannot be decoded warns and returns a NONE handle (the reference asserts)
+  rt_material_handle add_lambert_material(const std::string &file_path);
   rt_material_handle add_metal_material(vec3 albedo, float fuzz);
   rt_material_handle add_dielectric_material(float refractive_index);
   rt_material_handle add_emissive_material(vec3 intensity);

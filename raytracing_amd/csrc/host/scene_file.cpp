@@ -355,9 +355,19 @@ int64_t instantiate_scene(const SceneFile &scene, Renderer &renderer, std::strin
         continue;
       rt_material_handle mat = fallback;
       int mi = obj.group_material[g];
-      if (mi >= 0) { // every .mtl entry becomes a Lambert from Kd (Scene.cpp:58-70); map_Kd is not decoded here
+      if (mi >= 0) { // every .mtl entry becomes a Lambert: from map_Kd if present, else from Kd (Scene.cpp:58-70)
         const ObjMaterial &om = obj.materials[(size_t)mi];
-        mat = renderer.add_lambert_material(vec3(om.kd[0], om.kd[1], om.kd[2]));
+        if (!om.map_kd.empty()) {
+          const size_t slash = m.path.find_last_of("/\\");
+          const std::string dir = slash == std::string::npos ? std::string(".") : m.path.substr(0, slash);
+          mat = renderer.add_lambert_material(dir + "/" + om.map_kd); // Scene.cpp:63-65
+          if (mat.type == RT_MATERIAL_NONE) {
+            err = m.path + ": material '" + om.name + "': " + renderer.last_error();
+            return -1;
+          }
+        } else {
+          mat = renderer.add_lambert_material(vec3(om.kd[0], om.kd[1], om.kd[2]));
+        }
       }
       uint32_t blas = renderer.add_blas(mesh.positions.data(), mesh.normals.data(), mesh.uvs.data(),
                                         mesh.indices.data(), mesh.indices.size());

@@ -42,7 +42,7 @@ struct SceneFile {
 bool load_scene_file(const std::string &json_path, SceneFile &out, std::string &err);
 
 // Loads every model into the renderer: one BLAS + one instance per OBJ material
-// group, Lambert from Kd, (0.8, 0, 0.8) for faces without a material
+// group, Lambert from the map_Kd image if the material has one, else from Kd, (0.8, 0, 0.8) for faces without a material
 // (Scene.cpp:58-70, 121-125, 182).  Returns the number of triangles added, or -1.
 int64_t instantiate_scene(const SceneFile &scene, Renderer &renderer, std::string &err);
 

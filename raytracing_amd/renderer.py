@@ -23,7 +23,8 @@ PLANE, CUBE, SPHERE = 0, 1, 2
 
 HOST_SYMBOLS = [
     "rth_create", "rth_destroy", "rth_resize", "rth_render", "rth_set_option", "rth_get_frame_index",
-    "rth_reset_accumulation", "rth_add_lambert_material", "rth_add_lambert_texture",
+    "rth_reset_accumulation", "rth_add_lambert_material", "rth_add_lambert_texture", "rth_add_lambert_image",
+    "rth_decode_image",
     "rth_add_metal_material", "rth_add_dielectric_material", "rth_add_emissive_material",
     "rth_remove_material", "rth_default_material", "rth_add_blas", "rth_add_blas_mesh",
     "rth_add_blas_instance", "rth_set_blas_instance_transform", "rth_remove_blas",
@@ -69,6 +70,9 @@ def lib():
     L.rth_reset_accumulation.argtypes = [vp]; L.rth_reset_accumulation.restype = None
     L.rth_add_lambert_material.argtypes = [vp, vp]; L.rth_add_lambert_material.restype = MH
     L.rth_add_lambert_texture.argtypes = [vp, C.c_int32, C.c_int32, vp]; L.rth_add_lambert_texture.restype = MH
+    L.rth_add_lambert_image.argtypes = [vp, C.c_char_p]; L.rth_add_lambert_image.restype = MH
+    L.rth_decode_image.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp, C.c_uint64, C.c_char_p, C.c_size_t]
+    L.rth_decode_image.restype = C.c_int
     L.rth_add_metal_material.argtypes = [vp, vp, f32]; L.rth_add_metal_material.restype = MH
     L.rth_add_dielectric_material.argtypes = [vp, f32]; L.rth_add_dielectric_material.restype = MH
     L.rth_add_emissive_material.argtypes = [vp, vp]; L.rth_add_emissive_material.restype = MH
@@ -118,6 +122,18 @@ def trs(position=(0, 0, 0), angle=0.0, axis=(0, 1, 0), scale=(1, 1, 1)):
     out = np.zeros(16, np.float32)
     lib().rth_trs(T.ptr(_f32(position)), np.float32(angle), T.ptr(_f32(axis)), T.ptr(_f32(scale)), T.ptr(out))
     return out
+
+
+def decode_image(path):
+    """The host library's image decoder (stbi_load(path, .., 4) semantics): uint8 array [h, w, 4]."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    err = C.create_string_buffer(512)
+    if lib().rth_decode_image(os.fsencode(path), C.byref(w), C.byref(h), None, 0, err, len(err)) != 0:
+        raise RendererError(err.value.decode(errors="replace"))
+    px = np.zeros((h.value, w.value, 4), np.uint8)
+    if lib().rth_decode_image(os.fsencode(path), C.byref(w), C.byref(h), T.ptr(px), px.size, err, len(err)) != 0:
+        raise RendererError(err.value.decode(errors="replace"))
+    return px
 
 
 class Mesh:
@@ -243,6 +259,10 @@ class Renderer:
     def add_lambert_texture(self, width, height, rgba8):
         px = np.ascontiguousarray(rgba8, np.uint8)
         return lib().rth_add_lambert_texture(self._h, width, height, T.ptr(px))
+
+    def add_lambert_image(self, path):
+        """add_lambert_material(file_path), Renderer.cpp:705-716 (PNG / binary PNM)."""
+        return lib().rth_add_lambert_image(self._h, os.fsencode(path))
 
     def add_metal_material(self, albedo, fuzz):
         return lib().rth_add_metal_material(self._h, T.ptr(_f32(albedo)), fuzz)
