@@ -138,6 +138,12 @@ uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instan
 void rth_tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids,
                      uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes);
 uint32_t rth_tlas_cluster(rt_tlas_node *nodes, uint32_t n);
+/* glTF 2.0 import (.gltf / .glb) as the reference's load_gltf_scene + update_transforms do it
+ * (src/SceneGraph.cpp:168-407, :544-566): Lamberts from the materials, one BLAS + instance per triangle primitive,
+ * transforms down the node hierarchy below `parent_global16` (column-major 4x4; NULL = identity).  Returns the number
+ * of triangles added or -1 (message in err); counts[4] (optional) = nodes, meshes, primitives, materials. */
+int64_t rth_import_gltf(rth_renderer *r, const char *path, const float *parent_global16, uint32_t *counts,
+                        char *err, size_t err_len);
 /* 1 if the renderer's last TLAS build ran its clustering loop on the GPU; *kernel_ms (optional) = its kernel time */
 int rth_last_tlas_build(rth_renderer *r, float *kernel_ms);
 void rth_mat4_inverse(const float *m16, float *out16);

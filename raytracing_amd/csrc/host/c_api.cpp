@@ -7,6 +7,7 @@
 #include "../../../include/rt_host.h"
 #include "accel_build.h"
 #include "meshes.h"
+#include "gltf_file.h"
 #include "image_decode.h"
 #include "renderer.h"
 #include "scene_file.h"
@@ -308,6 +309,22 @@ uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instan
                         const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                         const rt_bvh_node *bvh_nodes) {
   return rta::build_tlas(tlas_nodes, instances, instance_ids, n, blas, bvh_nodes);
+}
+int64_t rth_import_gltf(rth_renderer *r, const char *path, const float *parent_global16, uint32_t *counts,
+                        char *err, size_t err_len) {
+  std::string e;
+  int64_t n = -1;
+  if (!r || !path) {
+    e = "rth_import_gltf: NULL argument";
+  } else {
+    rta::GltfImportInfo info;
+    n = rta::import_gltf(path, r->r, parent_global16 ? rta::mat4(parent_global16) : rta::mat4(1.f), e, &info);
+    if (n >= 0 && counts)
+      counts[0] = info.nodes, counts[1] = info.meshes, counts[2] = info.primitives, counts[3] = info.materials;
+  }
+  if (n < 0 && err && err_len)
+    snprintf(err, err_len, "%s", e.c_str());
+  return n;
 }
 void rth_tlas_leaves(rt_tlas_node *leaves, const rt_blas_instance *instances, const uint32_t *instance_ids,
                      uint32_t n, const rt_blas *blas, const rt_bvh_node *bvh_nodes) {

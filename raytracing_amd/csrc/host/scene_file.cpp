@@ -1,6 +1,10 @@
 // scene_file.cpp — JSON scene files (see scene_file.h).
 #include "scene_file.h"
 
+#include <ctype.h>
+
+#include "gltf_file.h"
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -346,6 +350,17 @@ int64_t instantiate_scene(const SceneFile &scene, Renderer &renderer, std::strin
   // faces without a material: the loader's default Lambert, Scene.cpp:182
   rt_material_handle fallback = renderer.add_lambert_material(vec3(0.8f, 0.0f, 0.8f));
   for (const SceneModel &m : scene.models) {
+    const size_t dot = m.path.find_last_of('.');
+    std::string ext = dot == std::string::npos ? std::string() : m.path.substr(dot);
+    for (char &ch : ext)
+      ch = (char)tolower((unsigned char)ch);
+    if (ext == ".gltf" || ext == ".glb") { // a glTF asset attached under a node that carries the model's transform
+      const int64_t n = import_gltf(m.path, renderer, m.transform, err);
+      if (n < 0)
+        return -1;
+      triangles += n;
+      continue;
+    }
     ObjModel obj;
     if (!load_obj(m.path, obj, err))
       return -1;

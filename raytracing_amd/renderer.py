@@ -24,7 +24,7 @@ PLANE, CUBE, SPHERE = 0, 1, 2
 HOST_SYMBOLS = [
     "rth_create", "rth_destroy", "rth_resize", "rth_render", "rth_set_option", "rth_get_frame_index",
     "rth_reset_accumulation", "rth_add_lambert_material", "rth_add_lambert_texture", "rth_add_lambert_image",
-    "rth_decode_image",
+    "rth_decode_image", "rth_import_gltf",
     "rth_add_metal_material", "rth_add_dielectric_material", "rth_add_emissive_material",
     "rth_remove_material", "rth_default_material", "rth_add_blas", "rth_add_blas_mesh",
     "rth_add_blas_instance", "rth_set_blas_instance_transform", "rth_remove_blas",
@@ -73,6 +73,7 @@ def lib():
     L.rth_add_lambert_image.argtypes = [vp, C.c_char_p]; L.rth_add_lambert_image.restype = MH
     L.rth_decode_image.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp, C.c_uint64, C.c_char_p, C.c_size_t]
     L.rth_decode_image.restype = C.c_int
+    L.rth_import_gltf.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]; L.rth_import_gltf.restype = C.c_int64
     L.rth_add_metal_material.argtypes = [vp, vp, f32]; L.rth_add_metal_material.restype = MH
     L.rth_add_dielectric_material.argtypes = [vp, f32]; L.rth_add_dielectric_material.restype = MH
     L.rth_add_emissive_material.argtypes = [vp, vp]; L.rth_add_emissive_material.restype = MH
@@ -263,6 +264,17 @@ class Renderer:
     def add_lambert_image(self, path):
         """add_lambert_material(file_path), Renderer.cpp:705-716 (PNG / binary PNM)."""
         return lib().rth_add_lambert_image(self._h, os.fsencode(path))
+
+    def import_gltf(self, path, parent_global=None):
+        """load_gltf_scene + update_transforms (SceneGraph.cpp:168-407, 544-566): dict of counts."""
+        counts = np.zeros(4, np.uint32)
+        err = C.create_string_buffer(512)
+        pg = None if parent_global is None else T.ptr(np.ascontiguousarray(parent_global, np.float32).reshape(16))
+        n = lib().rth_import_gltf(self._h, os.fsencode(path), pg, T.ptr(counts), err, len(err))
+        if n < 0:
+            raise RendererError(err.value.decode(errors="replace"))
+        return {"triangles": int(n), "nodes": int(counts[0]), "meshes": int(counts[1]),
+                "primitives": int(counts[2]), "materials": int(counts[3])}
 
     def add_metal_material(self, albedo, fuzz):
         return lib().rth_add_metal_material(self._h, T.ptr(_f32(albedo)), fuzz)

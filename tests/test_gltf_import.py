@@ -1,0 +1,353 @@
+"""glTF import: load_gltf_scene + SceneGraph::update_transforms of the reference
+(src/SceneGraph.cpp:168-407, 544-566; Transform.hpp:15-33) restated in raytracing_amd/csrc/host/gltf_file.cpp.
+
+The tests author small assets (JSON + buffers, .gltf and .glb), build the scene the reference would build from them
+through the ORACLE's renderer — materials in asset order, breadth-first node walk, parent * local matrices computed
+with the oracle's glm restatements, the flat-normal and default-uv rules — and require the product's arrays to be
+equal bit for bit.  fastgltf and glm are third-party submodules absent from the snapshot, so this is parity with the
+documented behaviour of the reference's code, not with a run of it: parity unpinned."""
+import base64
+import json
+import math
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracing_amd import renderer as R
+from raytracing_amd import _types as T
+from . import _oracle as O
+from .test_image_decode import encode_png, expected_rgba
+
+F = np.float32
+IDENT = np.eye(4, dtype=F).reshape(-1)
+
+
+def _mul(a, b):
+    out = np.zeros(16, F)
+    O.lib().orc_mat4_mul(T.ptr(O.f32a(a)), T.ptr(O.f32a(b)), T.ptr(out))
+    return out
+
+
+def _quat_cast(m):  # glm::quat_cast(mat3), m[col][row], float32 step by step -> (w, x, y, z)
+    x2 = F(F(m[0][0] - m[1][1]) - m[2][2])
+    y2 = F(F(m[1][1] - m[0][0]) - m[2][2])
+    z2 = F(F(m[2][2] - m[0][0]) - m[1][1])
+    w2 = F(F(m[0][0] + m[1][1]) + m[2][2])
+    big, idx = w2, 0
+    for k, v in ((1, x2), (2, y2), (3, z2)):
+        if v > big:
+            big, idx = v, k
+    bv = F(np.sqrt(F(big + F(1))) * F(0.5))
+    mult = F(F(0.25) / bv)
+    a, b, c = F(F(m[1][2] - m[2][1]) * mult), F(F(m[2][0] - m[0][2]) * mult), F(F(m[0][1] - m[1][0]) * mult)
+    d, e, f = F(F(m[0][1] + m[1][0]) * mult), F(F(m[2][0] + m[0][2]) * mult), F(F(m[1][2] + m[2][1]) * mult)
+    return [(bv, a, b, c), (a, bv, d, e), (b, d, bv, f), (c, e, f, bv)][idx]
+
+
+def _local_matrix(node):
+    if "matrix" in node:  # Transform::set_transform then get_mat4
+        m = np.array(node["matrix"], np.float64).astype(F).reshape(4, 4)  # m[col][row]
+        pos = m[3][:3]
+        scl = [F(np.sqrt(F(F(F(c[0] * c[0]) + F(c[1] * c[1])) + F(c[2] * c[2])))) for c in m[:3]]
+        rot = [[F(m[k][r] / scl[k]) for r in range(3)] for k in range(3)]
+        return O.trs(pos, _quat_cast(rot), scl)
+    t = node.get("translation", [0, 0, 0])
+    r = node.get("rotation", [0, 0, 0, 1])
+    s = node.get("scale", [1, 1, 1])
+    return O.trs(t, (r[3], r[0], r[1], r[2]), s)
+
+
+class Builder:
+    """Authors an asset: accessors appended to one binary buffer."""
+
+    def __init__(self):
+        self.bin = bytearray()
+        self.views, self.accessors = [], []
+
+    def view(self, data, stride=None):
+        while len(self.bin) % 4:
+            self.bin.append(0)
+        v = {"buffer": 0, "byteOffset": len(self.bin), "byteLength": len(data)}
+        if stride:
+            v["byteStride"] = stride
+        self.bin += data
+        self.views.append(v)
+        return len(self.views) - 1
+
+    def accessor(self, array, comp, kind, normalized=False, view=None, offset=0, count=None):
+        a = {"componentType": comp, "type": kind, "count": int(count if count is not None else len(array))}
+        if view is None:
+            view = self.view(np.ascontiguousarray(array).tobytes())
+        a["bufferView"] = view
+        if offset:
+            a["byteOffset"] = offset
+        if normalized:
+            a["normalized"] = True
+        self.accessors.append(a)
+        return len(self.accessors) - 1
+
+
+def _author(tmp_path, glb=False, embed=True):
+    """-> (path, description for the expected side)."""
+    rng = np.random.default_rng(17)
+    b = Builder()
+
+    def mesh_data(nv, ntri):
+        pos = rng.uniform(-1, 1, (nv, 3)).astype(F)
+        nrm = rng.normal(size=(nv, 3)).astype(F)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(F)
+        uv = rng.uniform(0, 1, (nv, 2)).astype(F)
+        idx = rng.integers(0, nv, (ntri, 3)).astype(np.uint32)
+        return pos, nrm.astype(F), uv, idx
+
+    prims = []
+    # P0: float attributes in separate views, u16 indices
+    pos, nrm, uv, idx = mesh_data(12, 9)
+    prims.append(dict(pos=pos, nrm=nrm, uv=uv, idx=idx.reshape(-1),
+                      acc=dict(POSITION=b.accessor(pos, 5126, "VEC3"), NORMAL=b.accessor(nrm, 5126, "VEC3"),
+                               TEXCOORD_0=b.accessor(uv, 5126, "VEC2")),
+                      indices=b.accessor(idx.reshape(-1).astype(np.uint16), 5123, "SCALAR"), material=0))
+    # P1: interleaved position + normal (byteStride 24), u8 indices, normalized u8 texture coordinates
+    pos, nrm, uv, idx = mesh_data(10, 7)
+    inter = np.concatenate([pos, nrm], axis=1).astype(F)
+    v = b.view(inter.tobytes(), stride=24)
+    uv8 = rng.integers(0, 256, (10, 2)).astype(np.uint8)
+    uv8_padded = np.zeros((10, 4), np.uint8)  # element stride 4: vertex attributes are 4-byte aligned
+    uv8_padded[:, :2] = uv8
+    v_uv = b.view(uv8_padded.tobytes(), stride=4)
+    prims.append(dict(pos=pos, nrm=nrm, uv=(uv8.astype(F) / F(255.0)).astype(F), idx=idx.reshape(-1),
+                      acc=dict(POSITION=b.accessor(None, 5126, "VEC3", view=v, count=10),
+                               NORMAL=b.accessor(None, 5126, "VEC3", view=v, offset=12, count=10),
+                               TEXCOORD_0=b.accessor(None, 5121, "VEC2", normalized=True, view=v_uv, count=10)),
+                      indices=b.accessor(idx.reshape(-1).astype(np.uint8), 5121, "SCALAR"), material=1))
+    # P2: no normals (flat normals in index order), no uvs, no indices (generated), no material (default)
+    pos = rng.uniform(-1, 1, (9, 3)).astype(F)
+    prims.append(dict(pos=pos, nrm=None, uv=None, idx=np.arange(9, dtype=np.uint32),
+                      acc=dict(POSITION=b.accessor(pos, 5126, "VEC3")), indices=None, material=None))
+    # P3: u32 indices, texture from a bufferView image
+    pos, nrm, uv, idx = mesh_data(8, 6)
+    prims.append(dict(pos=pos, nrm=nrm, uv=uv, idx=idx.reshape(-1),
+                      acc=dict(POSITION=b.accessor(pos, 5126, "VEC3"), NORMAL=b.accessor(nrm, 5126, "VEC3"),
+                               TEXCOORD_0=b.accessor(uv, 5126, "VEC2")),
+                      indices=b.accessor(idx.reshape(-1), 5125, "SCALAR"), material=2))
+
+    tex_a = rng.integers(0, 256, (5, 6, 4), dtype=np.uint16)
+    tex_b = rng.integers(0, 256, (3, 4, 3), dtype=np.uint16)
+    png_a, png_b = encode_png(tex_a, 8, 6), encode_png(tex_b, 8, 2, interlace=True)
+    view_b = b.view(png_b)
+    if embed:
+        img_a = {"uri": "data:image/png;base64," + base64.b64encode(png_a).decode()}
+    else:
+        (tmp_path / "tex a.png").write_bytes(png_a)
+        img_a = {"uri": "tex%20a.png"}
+    c30, s30 = math.cos(0.3), math.sin(0.3)
+    doc = {
+        "asset": {"version": "2.0"},
+        "scene": 0,
+        "scenes": [{"nodes": [0, 3]}],  # two roots: the scene graph inserts a group node
+        "nodes": [
+            {"name": "A", "translation": [1.5, -0.25, 2.0], "rotation": [0.0, 0.3826834, 0.0, 0.9238795],
+             "scale": [2.0, 0.5, 1.25], "children": [1, 2]},
+            {"name": "B", "mesh": 0,  # two primitives -> Mesh_0 / Mesh_1 child nodes
+             "matrix": [1.5 * c30, 1.5 * s30, 0, 0, -0.75 * s30, 0.75 * c30, 0, 0, 0, 0, 2.0, 0, 0.5, 1.0, -3.0, 1]},
+            {"name": "C", "mesh": 1, "scale": [1, 1, -1]},
+            {"name": "D", "mesh": 2, "translation": [-2, 0, 0.5]},
+        ],
+        "meshes": [
+            {"primitives": [0, 1]}, {"primitives": [2]}, {"primitives": [3]}],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.25, 1.5, -0.5, 0.5]}},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 1}, "baseColorFactor": [0, 0, 0, 1]}},
+            {"name": "unused: still becomes a Lambert"}],
+        "textures": [{"source": 0}, {"source": 1}],
+        "images": [img_a, {"bufferView": view_b, "mimeType": "image/png"}],
+    }
+    for m in doc["meshes"]:
+        out = []
+        for p in m["primitives"]:
+            d = {"attributes": prims[p]["acc"]}
+            if prims[p]["indices"] is not None:
+                d["indices"] = prims[p]["indices"]
+            if prims[p]["material"] is not None:
+                d["material"] = prims[p]["material"]
+            out.append(d)
+        m["primitives"] = out
+    doc["bufferViews"], doc["accessors"] = b.views, b.accessors
+    if glb:
+        doc["buffers"] = [{"byteLength": len(b.bin)}]
+        js = json.dumps(doc).encode()
+        js += b" " * (-len(js) % 4)
+        binc = bytes(b.bin) + b"\0" * (-len(b.bin) % 4)
+        body = struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(binc), 0x004E4942) + binc
+        path = tmp_path / "asset.glb"
+        path.write_bytes(b"glTF" + struct.pack("<II", 2, 12 + len(body)) + body)
+    else:
+        (tmp_path / "asset.bin").write_bytes(bytes(b.bin))
+        doc["buffers"] = [{"byteLength": len(b.bin), "uri": "asset.bin"}]
+        path = tmp_path / "asset.gltf"
+        path.write_text(json.dumps(doc))
+    desc = dict(doc=doc, prims=prims, mesh_prims=[[0, 1], [2], [3]],
+                textures=[expected_rgba(tex_a, 8, 6), expected_rgba(tex_b, 8, 2)])
+    return str(path), desc
+
+
+def _expected(desc, parent=IDENT, extra_before=None):
+    """The scene the reference's importer would assemble, through the oracle's renderer."""
+    o = O.OracleRenderer()
+    for which in (0, 1, 2):
+        o.add_blas(*R.Mesh.primitive(which).arrays())
+    if extra_before:
+        extra_before(o)
+    doc = desc["doc"]
+    mats = []
+    for m in doc["materials"]:  # SceneGraph.cpp:199-223
+        pbr = m.get("pbrMetallicRoughness", {})
+        if "baseColorTexture" in pbr:
+            tex = desc["textures"][doc["textures"][pbr["baseColorTexture"]["index"]]["source"]]
+            mats.append(o.add_lambert_texture(tex.shape[1], tex.shape[0], tex.reshape(-1)))
+        else:
+            f = np.clip(np.array(pbr.get("baseColorFactor", [1, 1, 1, 1]), np.float64).astype(F), F(0), F(1))
+            mats.append(o.add_lambert_texture(1, 1, (f * F(255.0)).astype(np.uint8)))
+    roots = doc["scenes"][doc.get("scene", 0)]["nodes"]
+    roots_parent = O.f32a(parent) if len(roots) == 1 else _mul(parent, IDENT)
+    queue = [(k, roots_parent) for k in roots]
+    while queue:
+        k, pg = queue.pop(0)
+        node = doc["nodes"][k]
+        g = _mul(pg, _local_matrix(node))
+        queue += [(c, g) for c in node.get("children", [])]
+        if "mesh" not in node:
+            continue
+        plist = desc["mesh_prims"][node["mesh"]]
+        for p in plist:
+            pr = desc["prims"][p]
+            pos, idx = pr["pos"], pr["idx"]
+            if pr["nrm"] is None:  # :338-352: three copies of the face normal per triangle, read per vertex index
+                flat = []
+                for t in range(0, len(idx) - 2, 3):
+                    p0, p1, p2 = pos[idx[t]], pos[idx[t + 1]], pos[idx[t + 2]]
+                    e1, e2 = (p1 - p0).astype(F), (p2 - p0).astype(F)
+                    cr = np.array([F(F(e1[1] * e2[2]) - F(e2[1] * e1[2])), F(F(e1[2] * e2[0]) - F(e2[2] * e1[0])),
+                                   F(F(e1[0] * e2[1]) - F(e2[0] * e1[1]))], F)
+                    inv = F(F(1.0) / F(np.sqrt(F(F(F(cr[0] * cr[0]) + F(cr[1] * cr[1])) + F(cr[2] * cr[2])))))
+                    flat += [cr * inv] * 3
+                nrm = np.array(flat, F)
+            else:
+                nrm = pr["nrm"]
+            uv = pr["uv"] if pr["uv"] is not None else np.zeros((len(pos), 2), F)
+            blas = o.add_blas(pos, nrm, uv, idx)
+            mat = mats[pr["material"]] if pr["material"] is not None else o.default_material
+            inst = o.add_blas_instance(blas, IDENT, mat)
+            o.set_blas_instance_transform(inst, g if len(plist) == 1 else _mul(g, IDENT))
+    return o.build()
+
+
+def _same_scene(got, want):
+    for name in ("tri_geom", "tri_shading", "tri_ids", "bvh_nodes", "blas", "instances", "lamberts", "textures", "texels"):
+        assert getattr(got, name).tobytes() == getattr(want, name).tobytes(), name
+    n = want.tlas_node_count
+    assert got.tlas_node_count == n and got.tlas_nodes[:n].tobytes() == want.tlas_nodes[:n].tobytes()
+
+
+@pytest.mark.parametrize("glb,embed", [(False, True), (False, False), (True, True)])
+def test_import_builds_the_scene_the_reference_importer_would(tmp_path, glb, embed):
+    path, desc = _author(tmp_path, glb, embed)
+    r = R.Renderer(8, 8, device=None)
+    info = r.import_gltf(path)
+    assert info == {"triangles": 9 + 7 + 3 + 6, "nodes": 4, "meshes": 3, "primitives": 4, "materials": 4}
+    _same_scene(r.scene_arrays(), _expected(desc))
+
+
+def test_import_below_a_transformed_parent_node(tmp_path):
+    path, desc = _author(tmp_path)
+    parent = O.trs((3, 1, -2), O.angle_axis(F(0.7), [0, 0, 1]), (0.5, 0.5, 0.5))
+    r = R.Renderer(8, 8, device=None)
+    r.import_gltf(path, parent)
+    _same_scene(r.scene_arrays(), _expected(desc, parent))
+
+
+def test_bad_assets_are_reported(tmp_path):
+    path, desc = _author(tmp_path)
+    base = desc["doc"]
+
+    def variant(name, edit):
+        doc = json.loads(json.dumps(base))
+        edit(doc)
+        p = tmp_path / name
+        p.write_text(json.dumps(doc))
+        return str(p)
+
+    cases = {
+        "sparse": lambda d: d["accessors"][0].update(sparse={"count": 1}),
+        "mode": lambda d: d["meshes"][0]["primitives"][0].update(mode=1),
+        "range": lambda d: d["accessors"][0].update(count=4000),
+        "index": lambda d: d["accessors"][d["meshes"][2]["primitives"][0]["indices"]].update(bufferView=0),
+        "cycle": lambda d: d["nodes"][2].update(children=[0]),
+        "nomesh": lambda d: d["nodes"][3].update(mesh=7),
+        "noscene": lambda d: d.pop("scenes"),
+        "nobuf": lambda d: d["buffers"][0].update(uri="missing.bin"),
+        "jpeg": lambda d: d["images"][0].update(uri="data:image/jpeg;base64," + base64.b64encode(b"\xff\xd8\xff\xe0" + b"\0" * 32).decode()),
+        "remote": lambda d: d["images"][0].update(uri="https://example.invalid/a.png"),
+    }
+    for name, edit in cases.items():
+        with pytest.raises(R.RendererError):
+            R.Renderer(8, 8, device=None).import_gltf(variant(name + ".gltf", edit))
+    (tmp_path / "broken.gltf").write_text("{ not json")
+    with pytest.raises(R.RendererError):
+        R.Renderer(8, 8, device=None).import_gltf(str(tmp_path / "broken.gltf"))
+    (tmp_path / "short.glb").write_bytes(b"glTF" + struct.pack("<II", 2, 4000))
+    with pytest.raises(R.RendererError):
+        R.Renderer(8, 8, device=None).import_gltf(str(tmp_path / "short.glb"))
+    with pytest.raises(R.RendererError, match="cannot open"):
+        R.Renderer(8, 8, device=None).import_gltf(str(tmp_path / "none.gltf"))
+
+
+def _scene_json(tmp_path, asset):
+    scene = {"camera": {"screen_width": 96, "aspect_ratio": 1.5, "samples_per_pixel": 4, "max_depth": 4,
+                        "vfov_deg": 50.0, "center": [1.0, 1.5, 12.0], "lookat": [0.5, 0, 0], "vup": [0, 1, 0],
+                        "defocus_angle": 0.0, "focus_dist": 1.0},
+             "models": [{"model_path": os.path.basename(asset), "scale": 1.5, "translation": [0.25, 0.5, -1.0]}]}
+    p = tmp_path / "scene.json"
+    p.write_text(json.dumps(scene))
+    return str(p), scene
+
+
+def _scene_parent(model):
+    from .test_scene_file import _expected_transform
+    return _expected_transform(model)
+
+
+def test_scene_file_with_a_gltf_model(tmp_path):
+    asset, desc = _author(tmp_path, glb=True)
+    path, scene = _scene_json(tmp_path, asset)
+    r = R.Renderer(8, 8, device=None)
+    cam, info = r.load_scene_file(path)
+    assert info["triangles"] == 25
+    want = _expected(desc, _scene_parent(scene["models"][0]),
+                     extra_before=lambda o: o.add_lambert_material((0.8, 0.0, 0.8)))  # the loader's fallback Lambert
+    _same_scene(r.scene_arrays(), want)
+
+
+@pytest.mark.gpu
+def test_cli_renders_a_gltf_model_bit_exactly(tmp_path):
+    asset, desc = _author(tmp_path, glb=True)
+    path, scene = _scene_json(tmp_path, asset)
+    cli = os.path.join(os.path.dirname(os.path.abspath(R.__file__)), "bin", "renderer")
+    raw = str(tmp_path / "out.f32")
+    p = subprocess.run([cli, path, "-hip", "-o", str(tmp_path / "out.png"), "--raw", raw], capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    c = scene["camera"]
+    w, h = 96, 64
+    got = np.fromfile(raw, np.float32).reshape(h, w, 4)
+    host = R.Renderer(w, h, device=None)
+    camu = host.camera_uniforms(R.Camera(c["center"], c["lookat"], c["vup"], c["vfov_deg"], 0.0, 1.0))
+    sc = _expected(desc, _scene_parent(scene["models"][0]),
+                   extra_before=lambda o: o.add_lambert_material((0.8, 0.0, 0.8)))
+    want = O.render(sc, camu, O.render_params(w, h, 0, 2, c["max_depth"]), nthreads=8)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got[..., :3] != got[0, 0, :3]).any()
