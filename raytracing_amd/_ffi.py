@@ -25,6 +25,9 @@ SYMBOLS = [
 ]
 
 
+KERNEL_VARIANT_AUTO = 0xFFFFFFFF  # RT_KERNEL_VARIANT_AUTO: rt_render chooses (a new context's state)
+
+
 class Stats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("last_kernel_ms", C.c_double),
                 ("total_kernel_ms", C.c_double), ("launches", C.c_uint64),

@@ -99,6 +99,7 @@ struct rt_ctx {
   rt_camera_uniforms camera{};
   bool have_camera = false;
   uint32_t variant = 5; // persistent, regenerating, vote-scheduled resumable traversal (k_render_v2<.., SCHED=1>)
+  bool variant_auto = true; // rt_render chooses between variants 5 and 0 (RT_KERNEL_VARIANT_AUTO)
   uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
   uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
   // timing
@@ -520,7 +521,14 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (pc.row_begin >= pc.row_end)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty row range");
   HIP_TRY(hipSetDevice(ctx->device));
-  const uint32_t kind = ctx->variant & 0xFFu;
+  // Kernel choice when the caller set none (tools/bench_lowspp.py): the vote-scheduled persistent kernel, except
+  // for a tiny scene rendered with a few short paths per pixel — the reference's live configuration, built-in
+  // Cornell box at 1 sample and depth 3 per frame — where every lane runs the same few steps and the plain
+  // one-lane-per-pixel kernel is 1.3x faster (0.40 vs 0.53 ms at 1280x720).  All kernels give the same bits.
+  // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
+  const uint32_t variant = !ctx->variant_auto ? ctx->variant
+                           : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 5u;
+  const uint32_t kind = variant & 0xFFu;
   const bool wavefront = kind == 4 && pc.max_depth > 0 && pc.max_depth <= 255 &&
                          (uint64_t)pc.sqrt_spp * pc.sqrt_spp < (1u << 24);
   if (wavefront) {
@@ -541,7 +549,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (rc != RT_OK)
     return rc;
   if (kind == 7) {
-    HIP_TRY(rt_launch_render_v7(ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
+    HIP_TRY(rt_launch_render_v7(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
                                 ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
                                 effective_regen_idle(ctx), ctx->stream));
   } else if (wavefront) {
@@ -549,7 +557,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
                                        ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->cus, ctx->stream));
   } else {
-    HIP_TRY(rt_launch_render(kind == 4 ? 2u : ctx->variant, ctx->dev, ctx->camera, pc, ctx->accum,
+    HIP_TRY(rt_launch_render(kind == 4 ? 2u : variant, ctx->dev, ctx->camera, pc, ctx->accum,
                              ctx->counter.ptr, ctx->queue.ptr, effective_regen_idle(ctx), ctx->cus, ctx->stream));
   }
   return end_timed(ctx, ev);
@@ -769,8 +777,13 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
 }
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
+  if (ctx && variant == RT_KERNEL_VARIANT_AUTO) {
+    ctx->variant_auto = true, ctx->variant = 5, ctx->regen_idle = 0;
+    return RT_OK;
+  }
   if (!ctx || (variant & 0xFFu) > 7)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
+  ctx->variant_auto = false;
   // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: per-kernel experiment knobs (rt_kernels.hip)
   ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);
   ctx->regen_idle = (variant >> 8) & 0xFFu; // 0: chosen by scene size (effective_regen_idle)

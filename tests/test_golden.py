@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from raytracing_amd import _ffi
 from raytracing_amd import _types as T
 from . import _golden as G
 from . import _oracle as O
@@ -90,5 +91,5 @@ def test_hip_reproduces_golden_images(ctx, name, variant):
     for f in range(frames):
         ctx.render(O.render_params(w, h, f, sqrt_spp, depth, rng_mode=rng))
     got = ctx.read_accum(w, h)
-    ctx.set_kernel_variant(5)  # back to the default
+    ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)  # back to the default
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -121,7 +121,7 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng, variant):
         ctx.render(p)
         O.render(sc, cam, p, want, nthreads=8)
     got = ctx.read_accum(w, h)
-    ctx.set_kernel_variant(5)  # back to the default
+    ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)  # back to the default
     assert np.isfinite(got).all()
     _same_image(got, want)
 
@@ -149,7 +149,7 @@ def test_image_bit_exact_outside_fast_slab_preconditions(ctx, kind, cam_pos, mod
     ctx.render(p)
     want = O.render(sc, cam, p, nthreads=8)
     got = ctx.read_accum(w, h)
-    ctx.set_kernel_variant(5)  # back to the default
+    ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)  # back to the default
     _same_image(got, want)
 
 
@@ -172,7 +172,7 @@ def test_rays_counted_and_rows(ctx, variant):
     got = ctx.read_accum(w, h)
     _same_image(got, want)
     st = ctx.stats()
-    ctx.set_kernel_variant(5)  # back to the default
+    ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)  # back to the default
     assert st.rays_traced == cn.rays and st.launches == 2 and st.total_kernel_ms > 0
 
 
@@ -284,3 +284,26 @@ def test_defocus_blur_c5_camera(ctx):
             pr.row_begin, pr.row_end = rows
             ctx.render(pr)
         _same_image(ctx.read_accum(w, h), O.render(sc, cam, p, nthreads=8))
+
+
+@pytest.mark.parametrize("sqrt_spp,depth", [(1, 3), (2, 3), (1, 8), (4, 3)])
+def test_automatic_kernel_choice_is_bit_exact(sqrt_spp, depth):
+    """A new context chooses the kernel itself (RT_KERNEL_VARIANT_AUTO): the one-lane-per-pixel kernel for the
+    reference's live configuration (tiny scene, <= 4 samples, depth <= 3), the vote-scheduled one otherwise."""
+    c = _ffi.HipContext(0)
+    try:
+        make, camf = SCENES["cornell"]
+        sc = make().build()
+        c.upload_scene(sc)
+        w, h = 100, 52
+        cam = camf(w, h)
+        c.set_camera(cam)
+        c.resize(w, h)
+        want = np.zeros((h, w, 4), np.float32)
+        for frame in range(2):
+            p = O.render_params(w, h, frame, sqrt_spp, depth)
+            c.render(p)
+            O.render(sc, cam, p, want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
+    finally:
+        c.close()

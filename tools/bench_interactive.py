@@ -11,7 +11,7 @@ from tests.test_host_parity import _cornell_via_product
 W, H, FRAMES = 1280, 720, 300
 r = _cornell_via_product(device=0, w=W, h=H)
 cam = R.Camera((0, 0.75, 1.5), (0, 0.75, -1), (0, 1, 0), 90.0)
-for variant in (5, 0):
+for variant in (_ffi.KERNEL_VARIANT_AUTO, 5, 0):
     r.set_option(R.OPT_KERNEL_VARIANT, variant)
     for _ in range(20):
         r.render(cam)
@@ -24,5 +24,5 @@ for variant in (5, 0):
     r.wait()
     dt = time.perf_counter() - t0
     st = _ffi.Stats(); _ffi._check(L.rt_get_stats(ctx, C.byref(st)))
-    print(f"variant {variant}: {FRAMES/dt:8.1f} frames/s wall, kernel {st.total_kernel_ms/FRAMES*1e3:7.1f} us/frame, "
+    print(f"variant {'auto' if variant == _ffi.KERNEL_VARIANT_AUTO else variant}: {FRAMES/dt:8.1f} frames/s wall, kernel {st.total_kernel_ms/FRAMES*1e3:7.1f} us/frame, "
           f"{st.rays_traced/dt/1e6:8.1f} Mrays/s wall, {st.rays_traced/st.total_kernel_ms/1e3:8.1f} Mrays/s in-kernel")
