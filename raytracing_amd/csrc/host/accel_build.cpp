@@ -254,9 +254,16 @@ uint32_t tlas_cluster(rt_tlas_node *out, uint32_t n) {
   for (uint32_t k = 0; k < n; ++k)
     live[k] = (int)(k + 1);
   int remaining = (int)n;
-  int a = 0, b = best_match(out, live, remaining, a); // TLAS.cpp:39-55
+  // find_best_match returns -1 when no union area is below +inf (boxes with inf / NaN extents or areas that
+  // overflow); the reference then indexes its list with -1.  Any other cluster is taken instead, so that the
+  // loop terminates with a valid tree.
+  auto match = [&](int of) {
+    const int m = best_match(out, live, remaining, of);
+    return m >= 0 ? m : (of == 0 ? 1 : 0);
+  };
+  int a = 0, b = remaining > 1 ? match(a) : -1; // TLAS.cpp:39-55
   while (remaining > 1) {
-    int c = best_match(out, live, remaining, b);
+    int c = match(b);
     if (a == c) {
       const int ia = live[a], ib = live[b];
       rt_tlas_node &merged = out[count];
@@ -266,7 +273,8 @@ uint32_t tlas_cluster(rt_tlas_node *out, uint32_t n) {
       max(vec3(out[ia].aabb_max), vec3(out[ib].aabb_max)).store(merged.aabb_max);
       live[a] = (int)count++;
       live[b] = live[remaining - 1];
-      b = best_match(out, live, --remaining, a);
+      --remaining;
+      b = remaining > 1 ? match(a) : -1;
     } else {
       a = b;
       b = c;

@@ -84,6 +84,24 @@ def test_host_cluster_is_a_valid_tree(kind, n):
     assert sorted(leaves) == list(range(n)) and seen.max() == 1
 
 
+def test_host_cluster_survives_non_finite_boxes():
+    """Where the reference's loop would index its list with -1 (no union area below +inf), the host builder still
+    returns a tree over all leaves."""
+    lv = _leaves(9, 1)
+    lv["aabb_max"][:] = np.inf
+    nodes, cnt = _host_cluster(lv)
+    assert cnt == 17
+    seen, stack = [], [0]
+    while stack:
+        k = stack.pop()
+        lr = int(nodes[k]["left_right"])
+        if lr == 0:
+            seen.append(int(nodes[k]["blas_instance_idx"]))
+        else:
+            stack += [lr & 0xFFFF, lr >> 16]
+    assert sorted(seen) == list(range(9))
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def ctx():
