@@ -130,6 +130,9 @@ int64_t rth_load_scene_file(rth_renderer *r, const char *json_path, rth_scene_in
 /* Builders on their own (tests compare them with the oracle's). */
 uint32_t rth_build_blas(rt_bvh_node *nodes, const rt_triangle_geom *tris, const float *centroids,
                         uint32_t *tri_ids, uint32_t tri_count, uint32_t first);
+/* BLAS::refit, src/BVHNode.cpp:163-177: recomputes the boxes of an existing tree bottom-up after its triangles
+ * moved (topology and leaf order kept) */
+void rth_refit_blas(rt_bvh_node *nodes, uint32_t nodes_count, const rt_triangle_geom *tris, const uint32_t *tri_ids);
 uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instances,
                         const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                         const rt_bvh_node *bvh_nodes);

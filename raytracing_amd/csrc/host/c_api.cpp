@@ -305,6 +305,9 @@ uint32_t rth_build_blas(rt_bvh_node *nodes, const rt_triangle_geom *tris, const 
                         uint32_t *tri_ids, uint32_t tri_count, uint32_t first) {
   return rta::build_blas(nodes, tris, centroids, tri_ids, tri_count, first);
 }
+void rth_refit_blas(rt_bvh_node *nodes, uint32_t nodes_count, const rt_triangle_geom *tris, const uint32_t *tri_ids) {
+  rta::refit_blas(nodes, nodes_count, tris, tri_ids);
+}
 uint32_t rth_build_tlas(rt_tlas_node *tlas_nodes, const rt_blas_instance *instances,
                         const uint32_t *instance_ids, uint32_t n, const rt_blas *blas,
                         const rt_bvh_node *bvh_nodes) {

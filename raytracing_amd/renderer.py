@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "rth_camera_uniforms", "rth_read_image", "rth_wait", "rth_context", "rth_last_error", "rth_trs",
     "rth_make_primitive", "rth_make_dragon", "rth_load_obj", "rth_load_scene_file", "rth_mesh_free", "rth_mesh_vertex_count",
     "rth_mesh_index_count", "rth_mesh_positions", "rth_mesh_normals", "rth_mesh_uvs",
-    "rth_mesh_indices", "rth_build_blas", "rth_build_tlas", "rth_tlas_leaves", "rth_tlas_cluster",
+    "rth_mesh_indices", "rth_build_blas", "rth_refit_blas", "rth_build_tlas", "rth_tlas_leaves", "rth_tlas_cluster",
     "rth_last_tlas_build", "rth_mat4_inverse",
 ]
 
@@ -105,6 +105,7 @@ def lib():
     for n in ("rth_mesh_positions", "rth_mesh_normals", "rth_mesh_uvs", "rth_mesh_indices"):
         getattr(L, n).argtypes = [vp]; getattr(L, n).restype = vp
     L.rth_build_blas.argtypes = [vp, vp, vp, vp, u32, u32]; L.rth_build_blas.restype = u32
+    L.rth_refit_blas.argtypes = [vp, u32, vp, vp]; L.rth_refit_blas.restype = None
     L.rth_build_tlas.argtypes = [vp, vp, vp, u32, vp, vp]; L.rth_build_tlas.restype = u32
     L.rth_tlas_leaves.argtypes = [vp, vp, vp, u32, vp, vp]; L.rth_tlas_leaves.restype = None
     L.rth_tlas_cluster.argtypes = [vp, u32]; L.rth_tlas_cluster.restype = u32

@@ -76,6 +76,34 @@ def test_blas_builder_equals_oracle(name, mesh):
     assert np.array_equal(ids, o.tri_ids)
 
 
+def test_blas_refit_equals_oracle_and_bounds_the_moved_triangles():
+    """BLAS::refit (BVHNode.cpp:163-177): same boxes as the oracle's refit after the vertices moved; every node still
+    contains its subtree's triangles; topology untouched."""
+    o = O.OracleRenderer()
+    o.add_blas(*S.load_obj(os.path.join(S.ASSETS, "teapot.obj")))
+    n, count = len(o.tri_ids), int(o.blas[0]["nodes_count"])
+    rng = np.random.default_rng(4)
+    geom = o.geom.copy()
+    for f in ("v0", "v1", "v2"):
+        geom[f][:, :3] += rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+    want, got = o.nodes[:count].copy(), o.nodes[:count].copy()
+    O.lib().orc_refit_blas(T.ptr(want), count, T.ptr(geom), T.ptr(o.tri_ids))
+    R.lib().rth_refit_blas(T.ptr(got), count, T.ptr(geom), T.ptr(o.tri_ids))
+    _same_struct(got, want)
+    assert np.array_equal(got["local_left_first"], o.nodes[:count]["local_left_first"])
+    assert np.array_equal(got["tri_count"], o.nodes[:count]["tri_count"])
+    assert not np.array_equal(got["aabb_min"], o.nodes[:count]["aabb_min"])
+    for k in range(count):
+        nd = got[k]
+        if nd["tri_count"]:
+            ids = o.tri_ids[nd["local_left_first"]: nd["local_left_first"] + nd["tri_count"]]
+            pts = np.concatenate([geom[f][ids][:, :3] for f in ("v0", "v1", "v2")])
+            assert (pts >= nd["aabb_min"]).all() and (pts <= nd["aabb_max"]).all()
+        else:
+            for c in (got[nd["local_left_first"]], got[nd["local_left_first"] + 1]):
+                assert (c["aabb_min"] >= nd["aabb_min"]).all() and (c["aabb_max"] <= nd["aabb_max"]).all()
+
+
 def test_blas_builder_nonzero_offset():
     # a second BLAS lives at a non-zero tri-id offset: leaf indices are global
     o = O.OracleRenderer()
