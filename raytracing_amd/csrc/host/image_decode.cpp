@@ -330,7 +330,7 @@ bool decode_png(const std::vector<uint8_t> &f, Image &img, std::string &err) {
         err = "PNG: unsupported header";
         return false;
       }
-      if (pi.w > (1u << 24) || pi.h > (1u << 24) || (uint64_t)pi.w * pi.h > (1ull << 28)) { // stb_image's limit is 2^24 a side
+      if (pi.w > (1u << 24) || pi.h > (1u << 24) || (uint64_t)pi.w * pi.h > (1ull << 26)) { // stb_image: 2^24 a side; here also 64 Mpixel
         err = "PNG: image too large";
         return false;
       }
@@ -453,7 +453,7 @@ bool decode_pnm(const std::vector<uint8_t> &f, Image &img, std::string &err) {
   size_t pos = 2;
   uint32_t w, h, maxv;
   if (!pnm_token(f, pos, w) || !pnm_token(f, pos, h) || !pnm_token(f, pos, maxv) || pos >= f.size() || w == 0 ||
-      h == 0 || maxv == 0 || maxv > 65535 || (uint64_t)w * h > (1ull << 28)) {
+      h == 0 || maxv == 0 || maxv > 65535 || (uint64_t)w * h > (1ull << 26)) {
     err = "PNM: bad header";
     return false;
   }
