@@ -74,8 +74,9 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
     ap.add_argument("--variant", type=int, default=5)
-    ap.add_argument("--shard", choices=["frames", "rows"], default="frames",
-                    help="N>1: progressive frames round-robin + reduce (default), or row bands + all-gather")
+    ap.add_argument("--shard", choices=["frames", "rows", "interleave"], default="frames",
+                    help="N>1: progressive frames round-robin + reduce (default), contiguous row bands + all-gather, "
+                         "or interleaved 8-row groups + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -112,11 +113,16 @@ def main():
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
     r.set_option(R.OPT_MAX_DEPTH, args.depth)
     r.set_option(R.OPT_AABB_MODE, T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV)
-    bands = None
+    bands, interleave = None, None
     if args.shard == "rows" and world > 1:  # every rank renders its row band of every frame
         bands = [sharding.row_shard(k, world, H) for k in range(world)]
         r.set_option(R.OPT_ROW_BEGIN, bands[rank][0])
         r.set_option(R.OPT_ROW_END, bands[rank][1])
+    elif args.shard == "interleave" and world > 1:  # every rank renders row groups rank, rank+N, ... of every frame
+        interleave = sharding.row_interleave(rank, world, H)
+        r.set_option(R.OPT_ROW_BEGIN, interleave["row_begin"])
+        r.set_option(R.OPT_ROW_END, interleave["row_end"])
+        r.set_option(R.OPT_ROW_GROUP_STRIDE, interleave["row_group_stride"])
     else:
         shard = sharding.frame_shard(rank, world)
         r.set_option(R.OPT_FRAME_STRIDE, shard["frame_stride"])
@@ -135,7 +141,9 @@ def main():
         r.render(cam)          # one launch: args.spp samples for every pixel
         if world > 1:
             r.wait()           # kernel runs on the library's stream
-            if bands is not None:
+            if interleave is not None:
+                sharding.gather_interleaved(accum)       # every rank: the complete image, bit-exact
+            elif bands is not None:
                 sharding.gather_rows(accum, bands)       # every rank: the complete image, bit-exact
             else:
                 sharding.combine(accum, out=reduced, dst=0)  # rank 0: (1/N) * sum of the N running means
@@ -242,14 +250,15 @@ def main():
     out = {
         "metric": "Mrays/s (incl. bounces) dragon scene", "value": value, "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if bands is not None else "weak",
+        "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (bands is not None or interleave is not None) else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)", "triangles": n_tris,
                    "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
                    "rng": "wang", "aabb": args.aabb, "kernel_variant": args.variant,
-                   "sharding": ("none" if world == 1 else "row bands per rank, RCCL all-gather per step" if bands is not None
+                   "sharding": ("none" if world == 1 else "interleaved 8-row groups per rank, RCCL all-gather per step"
+                                if interleave is not None else "row bands per rank, RCCL all-gather per step" if bands is not None
                                 else "progressive frames round-robin over ranks, RCCL reduce per step")},
-        "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * world)),
+        "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * (1 if (bands is not None or interleave is not None) else world))),
         "rays_per_step": rays_total / args.steps, "kernel_ms_per_launch": kernel_ms,
         "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity,
     }

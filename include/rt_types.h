@@ -188,7 +188,9 @@ typedef struct rt_render_params {
   uint32_t aabb_mode;   /* enum rt_aabb_mode */
   uint32_t row_begin;   /* render rows [row_begin, row_end); 0,0 => all */
   uint32_t row_end;
-  uint32_t reserved[2];
+  uint32_t row_group_stride; /* 0 or 1: every row of the range; N: only the 8-row groups row_begin/8 + k*N
+                                (multi-GPU interleaving: rank r sets row_begin = 8 r, stride = N) */
+  uint32_t reserved;
 } rt_render_params;
 
 /* RNG selection (RayTracing.slang:71-72 is RT_RNG_WANG). */

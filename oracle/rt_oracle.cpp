@@ -1217,9 +1217,14 @@ extern "C" void orc_render(const rt_scene_desc *scene,
   std::vector<orc_counters> per(nthreads);
   memset(per.data(), 0, sizeof(orc_counters) * nthreads);
   auto work = [&](uint32_t tid) {
-    for (uint32_t y = y0 + tid; y < y1; y += nthreads)
+    // row_group_stride N > 1: only the 8-row groups 0, N, 2N, ... counted from row_begin (rt_types.h)
+    const uint32_t stride = params->row_group_stride ? params->row_group_stride : 1u;
+    for (uint32_t y = y0 + tid; y < y1; y += nthreads) {
+      if (((y - y0) >> 3) % stride != 0u)
+        continue;
       for (uint32_t x = 0; x < params->image_width; ++x)
         shade_pixel(scene, cam, params, x, y, accum, per[tid], nullptr);
+    }
   };
   if (nthreads == 1) {
     work(0);

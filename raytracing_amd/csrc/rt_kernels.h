@@ -9,6 +9,21 @@
 #include "../../include/rt_types.h"
 #include "rt_device_layout.h"
 
+// Rows of one launch.  A launch renders the rows y in [row_begin, row_end) that lie in the 8-row groups
+// row_begin/8 + k * row_group_stride (k = 0, 1, ...): stride 1 is a contiguous band, stride N with row_begin = 8 * r
+// is rank r's share of an image interleaved over N GPUs.  Kernels enumerate "virtual" rows 0 .. rt_virtual_rows - 1.
+static inline __host__ __device__ uint32_t rt_row_stride(const rt_render_params &pc) {
+  return pc.row_group_stride ? pc.row_group_stride : 1u;
+}
+static inline __host__ __device__ uint32_t rt_virtual_rows(const rt_render_params &pc) {
+  const uint32_t span = pc.row_end - pc.row_begin, step = 8u * rt_row_stride(pc);
+  const uint32_t full = span / step, rest = span - full * step;
+  return full * 8u + (rest < 8u ? rest : 8u);
+}
+static inline __host__ __device__ uint32_t rt_row(const rt_render_params &pc, uint32_t vrow) {
+  return pc.row_begin + (vrow >> 3) * 8u * rt_row_stride(pc) + (vrow & 7u);
+}
+
 // every box coordinate is 0 or of magnitude in [2^-66, 2^59]: the precondition of the
 // exact fast division of slab_pair_fast (rt_device_inl.h)
 #define RT_SCENE_BOXES_MODERATE 1u

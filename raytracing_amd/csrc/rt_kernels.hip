@@ -64,7 +64,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
   const uint32_t tile = xcd_band_tile(blockIdx.x, gridDim.x);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t x = (tile % tiles_x) * 16u + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t y = pc.row_begin + (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t y = rt_row(pc, (tile / tiles_x) * 16u + (wave >> 1) * 8u + (lane >> 3));
   uint32_t traced = 0;
   if (x < pc.image_width && y < pc.row_end) {
     Rng rng = make_rng(pc, x, y);
@@ -111,7 +111,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
   __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
   RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -143,7 +143,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
         } else {
           const uint32_t tile = slot >> 6, in = slot & 63u;
           x = (tile % tiles_x) * 8u + (in & 7u);
-          y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+          y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
           if (x < pc.image_width && y < pc.row_end) { // else: edge padding, fetch again
             have_pixel = true;
             have_path = false;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   }
   RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         if (slot < band_hi) { // else: retry on the next iteration (band just ran out)
           const uint32_t tile = slot >> 6, in = slot & 63u;
           x = (tile % tiles_x) * 8u + (in & 7u);
-          y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+          y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
           if (x < pc.image_width && y < pc.row_end) { // else edge padding: fetch again
             state = ST_NEWPATH;
             sample = 0;
@@ -927,7 +927,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                             const rt_render_params &pc, float *d_accum,
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
                             uint32_t cus, hipStream_t stream) {
-  uint32_t rows = pc.row_end - pc.row_begin;
+  uint32_t rows = rt_virtual_rows(pc);
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
   if ((variant & 0xFFu) == 0) {

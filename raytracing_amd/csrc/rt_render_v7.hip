@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(RT_BLOCK, MINW)
   extern __shared__ __align__(16) uint32_t lds_raw[];
   RT_STACK_DECL(RT_BLOCK, NLDS, st, lds_raw);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(RT_BLOCK, MINW)
           if (slot < total_slots) {
             const uint32_t tile = slot >> 6, in = slot & 63u;
             x = (tile % tiles_x) * 8u + (in & 7u);
-            y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+            y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
             if (x < pc.image_width && y < pc.row_end) { // else edge padding: fetch again
               sample = 0;
               seed = make_rng(pc, x, y).seed;
@@ -323,7 +323,7 @@ hipError_t rt_launch_render_v7(uint32_t variant, const rt_dev_scene &sc, const r
                                const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
                                uint32_t *d_queue, uint32_t *d_cold, uint32_t cus, uint32_t regen_idle,
                                hipStream_t stream) {
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
   if (pc.image_width > 0xFFFFu || pc.image_height > 0xFFFFu)
     return hipErrorInvalidValue; // pixel coordinates are packed 16:16 in the cold block

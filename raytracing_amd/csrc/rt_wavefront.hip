@@ -88,13 +88,13 @@ __device__ __forceinline__ Rng rng_of(const rt_render_params &pc, uint32_t p, co
 extern "C" __global__ void __launch_bounds__(256)
     k_wf_init(rt_wf_buffers b, rt_camera_uniforms cam, rt_render_params pc) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
   const uint32_t tile = slot >> 6, in = slot & 63u;
   const uint32_t x = (tile % tiles_x) * 8u + (in & 7u);
-  const uint32_t y = pc.row_begin + (tile / tiles_x) * 8u + (in >> 3);
+  const uint32_t y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
   const bool valid = slot < total_slots && x < pc.image_width && y < pc.row_end;
   const uint32_t p = y * pc.image_width + x;
   if (valid) {
@@ -490,7 +490,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
                                       uint32_t cus, hipStream_t stream) {
   if (cus == 0)
     return hipErrorInvalidValue;
-  const uint32_t rows = pc.row_end - pc.row_begin;
+  const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t slots = ((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
   hipError_t e = hipMemsetAsync(b.count, 0, 256, stream);
   if (e != hipSuccess)

@@ -14,6 +14,11 @@ rt_render_params.row_begin/row_end and the bands are all-gathered.  No floating
 point is re-associated, so the N-rank image equals the 1-rank image bit for bit;
 the price is load balance (a band of sky finishes early), which is why frames
 are the default for the bench.
+
+A third mode interleaves the rows (`row_interleave` / `gather_interleaved`): the
+image is cut into groups of 8 rows and rank r renders groups r, r+N, r+2N, ...
+(rt_render_params.row_group_stride), which spreads sky and geometry evenly over
+the ranks; the groups are all-gathered, again bit for bit equal to one GPU.
 """
 import torch
 import torch.distributed as dist
@@ -80,4 +85,52 @@ def gather_rows(image, rank_rows, group=None):
     for r, (rb, re) in enumerate(rank_rows):
         if r != rank and re > rb:
             image[rb:re].copy_(parts[r][: re - rb])
+    return image
+
+
+ROW_GROUP = 8  # rows per interleaving unit: the height of the kernels' pixel tiles
+
+
+def row_interleave(rank, world_size, height):
+    """Render options of rank `rank` for interleaved 8-row groups: dict with row_begin, row_end and
+    row_group_stride (rt_render_params), or None if the image has fewer groups than ranks and this
+    rank gets none."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    if rank * ROW_GROUP >= height:
+        return None
+    return {"row_begin": rank * ROW_GROUP, "row_end": height, "row_group_stride": world_size}
+
+
+def interleaved_rows(rank, world_size, height):
+    """Row indices rank `rank` renders under `row_interleave` (for tests and bookkeeping)."""
+    rows = []
+    for g in range(rank, (height + ROW_GROUP - 1) // ROW_GROUP, world_size):
+        rows.extend(range(g * ROW_GROUP, min((g + 1) * ROW_GROUP, height)))
+    return rows
+
+
+def gather_interleaved(image, group=None):
+    """All-gather the interleaved row groups: `image` is this rank's full-size (H, W, C) tensor
+    with its own groups filled in.  Returns the complete image on every rank (in place)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return image
+    rank = dist.get_rank(group)
+    height = image.shape[0]
+    groups = (height + ROW_GROUP - 1) // ROW_GROUP
+    per_rank = (groups + world - 1) // world
+    shape = (per_rank * ROW_GROUP,) + tuple(image.shape[1:])
+    mine = torch.zeros(shape, dtype=image.dtype, device=image.device)
+    for k, g in enumerate(range(rank, groups, world)):
+        rows = min(ROW_GROUP, height - g * ROW_GROUP)
+        mine[k * ROW_GROUP: k * ROW_GROUP + rows].copy_(image[g * ROW_GROUP: g * ROW_GROUP + rows])
+    parts = [torch.empty(shape, dtype=image.dtype, device=image.device) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    for r in range(world):
+        if r == rank:
+            continue
+        for k, g in enumerate(range(r, groups, world)):
+            rows = min(ROW_GROUP, height - g * ROW_GROUP)
+            image[g * ROW_GROUP: g * ROW_GROUP + rows].copy_(parts[r][k * ROW_GROUP: k * ROW_GROUP + rows])
     return image

@@ -172,3 +172,94 @@ def test_row_sharding_through_renderer_on_one_gpu():
     single = r.read_image()
     r.shutdown()
     assert np.array_equal(stitched.view(np.uint32), single.view(np.uint32))
+
+
+# ---- interleaved 8-row groups ("row-interleaved tiles round-robin over GPUs") -----------------------
+HI = 44  # 5 full groups + a partial one: ranks get 3 / 3 groups of unequal size
+
+
+def _interleave_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = S.cornell_builtin().build()
+        cam = S.cornell_camera(W, HI)
+        opt = sharding.row_interleave(rank, world, HI)
+        img = np.zeros((HI, W, 4), np.float32)
+        for f in range(2):  # this rank's row groups of every frame (the oracle stands in for the GPU)
+            O.render(sc, cam, O.render_params(W, HI, f, SQRT_SPP, DEPTH, **opt), img)
+        mine = sharding.interleaved_rows(rank, world, HI)
+        assert (np.delete(img, mine, axis=0) == 0).all() and (img[mine][..., 3] == 1).all()
+        full = sharding.gather_interleaved(torch.from_numpy(img))
+        np.save(out_path % rank, full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_interleaved_rows_equal_single_rank_bitwise(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "inter_%d.npy")
+    mp.spawn(_interleave_worker, args=(2, port, out), nprocs=2, join=True)
+    sc = S.cornell_builtin().build()
+    cam = S.cornell_camera(W, HI)
+    single = np.zeros((HI, W, 4), np.float32)
+    for f in range(2):
+        O.render(sc, cam, O.render_params(W, HI, f, SQRT_SPP, DEPTH), single)
+    for r in range(2):
+        assert np.array_equal(np.load(out % r).view(np.uint32), single.view(np.uint32))
+
+
+def test_row_interleave_bookkeeping():
+    for h in (1, 7, 8, 9, 24, 44, 1080, 2160):
+        for n in (1, 2, 3, 4, 8):
+            rows = [sharding.interleaved_rows(r, n, h) for r in range(n)]
+            assert sorted(sum(rows, [])) == list(range(h))
+            for r in range(n):
+                opt = sharding.row_interleave(r, n, h)
+                assert (opt is None) == (len(rows[r]) == 0)
+                if opt:
+                    assert opt == {"row_begin": 8 * r, "row_end": h, "row_group_stride": n}
+    assert sharding.interleaved_rows(1, 2, 20) == [8, 9, 10, 11, 12, 13, 14, 15]
+    with pytest.raises(ValueError):
+        sharding.row_interleave(2, 2, 100)
+    x = torch.ones(4, 2, 4)
+    assert sharding.gather_interleaved(x) is x  # no process group: nothing to gather
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7])
+def test_interleaved_rows_through_renderer_on_one_gpu(variant):
+    """Three renderers play three ranks of the interleaved mode: the stitched image is the single-renderer image
+    bit for bit, for every kernel family (they share the row mapping of rt_kernels.h)."""
+    from raytracing_amd import renderer as R
+    from .test_host_parity import _cornell_via_product
+    cam = R.Camera((0, 0.75, 1.5), (0, 0.75, -1), (0, 1, 0), 90.0)
+    world = 3
+
+    def make():
+        r = _cornell_via_product(device=0, w=W, h=HI)
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, SQRT_SPP * SQRT_SPP)
+        r.set_option(R.OPT_MAX_DEPTH, DEPTH)
+        r.set_option(R.OPT_KERNEL_VARIANT, variant)
+        return r
+
+    stitched = np.zeros((HI, W, 4), np.float32)
+    for rank in range(world):
+        r = make()
+        opt = sharding.row_interleave(rank, world, HI)
+        r.set_option(R.OPT_ROW_BEGIN, opt["row_begin"])
+        r.set_option(R.OPT_ROW_END, opt["row_end"])
+        r.set_option(R.OPT_ROW_GROUP_STRIDE, opt["row_group_stride"])
+        for _ in range(2):
+            r.render(cam)
+        img = r.read_image()
+        mine = sharding.interleaved_rows(rank, world, HI)
+        stitched[mine] = img[mine]
+        assert (np.delete(img, mine, axis=0) == 0).all()  # rows of the other ranks are untouched
+        r.shutdown()
+    r = make()
+    for _ in range(2):
+        r.render(cam)
+    single = r.read_image()
+    r.shutdown()
+    assert np.array_equal(stitched.view(np.uint32), single.view(np.uint32))
