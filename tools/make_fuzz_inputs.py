@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Inputs for tools/sanitize_host.sh: valid, truncated and byte-flipped PNG / glTF / GLB / OBJ / scene files."""
+import json, os, pathlib, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.test_image_decode import encode_png, _rand, CASES, CHANNELS
+from tests import test_gltf_import as G
+
+out = pathlib.Path(sys.argv[1] if len(sys.argv) > 1 else "/tmp/rt_fuzz")
+out.mkdir(parents=True, exist_ok=True)
+rng = np.random.default_rng(0)
+n = 0
+for color, depth, inter in CASES:
+    smp = _rand(rng, 17, 33, CHANNELS[color], depth)
+    pal = rng.integers(0, 256, (1 << depth, 3), dtype=np.uint8) if color == 3 else None
+    data = encode_png(smp, depth, color, pal, None, inter, 6)
+    (out / f"ok_{n}.png").write_bytes(data)
+    for k in range(6):
+        b = bytearray(data)
+        if k < 3:
+            b = b[:len(b) * (k + 1) // 5]
+        else:
+            for _ in range(4):
+                b[rng.integers(8, len(b))] = rng.integers(0, 256)
+        (out / f"bad_{n}_{k}.png").write_bytes(bytes(b))
+    n += 1
+
+
+def flips(raw, name, count, lo, hi, first=0, per=3):
+    for k in range(count):
+        b = bytearray(raw)
+        for _ in range(per):
+            b[rng.integers(first, len(b))] = rng.integers(lo, hi)
+        (out / name.format(k)).write_bytes(bytes(b))
+
+
+flips(open(G._author(out, glb=False, embed=True)[0], "rb").read(), "fuzz_{}.gltf", 40, 32, 127)
+flips(open(G._author(out, glb=True, embed=True)[0], "rb").read(), "fuzz_{}.glb", 40, 0, 256, first=12)
+flips(open(os.path.join(ROOT, "assets", "teapot.obj"), "rb").read()[:20000], "fuzz_{}.obj", 40, 32, 127, per=20)
+flips(open(os.path.join(ROOT, "assets", "scenes", "multi.json"), "rb").read(), "fuzz_{}.json", 40, 32, 127)
+(out / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -3\nf 1 2 9\nf 1/5/7 2/2/2 3/3/3\nf 0 0 0\nvt 1\nvn\nf 1 2\n")
+print(len(list(out.iterdir())), "files in", out)

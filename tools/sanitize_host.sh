@@ -1,0 +1,13 @@
+#!/bin/bash
+# Host loaders (image decoder, glTF / OBJ / scene-file parsers, Renderer edit flows) under AddressSanitizer +
+# UBSan on valid, truncated and byte-flipped inputs.  CPU only.  Usage: tools/sanitize_host.sh [workdir]
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+WORK=${1:-/tmp/rt_fuzz}
+python3 "$ROOT/tools/make_fuzz_inputs.py" "$WORK"
+cd "$ROOT/raytracing_amd/csrc/host"
+g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I. \
+    -o "$WORK/driver" "$ROOT/tools/sanitize_host_main.cpp" renderer.cpp accel_build.cpp meshes.cpp scene_file.cpp \
+    image_decode.cpp gltf_file.cpp -L../.. -lrt_hip -Wl,-rpath,"$ROOT/raytracing_amd"
+cd "$ROOT"
+"$WORK/driver" "$WORK"/*.png "$WORK"/*.gltf "$WORK"/*.glb "$WORK"/*.obj "$WORK"/*.json assets/scenes/*.json 2>&1 | grep -v "rta warn"
