@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
       // the other kinds wait; per lane the sequence of steps is unchanged.
       const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 3u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u; // measured on C3 (tools/compare_vote.sh): 2 -> 3012, 3 -> 2982 Mrays/s
       const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 6u;
       while (true) {
         const uint32_t kind =
