@@ -523,9 +523,11 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       // iteration is one section at good lane occupancy instead of every section
       // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
       // the other kinds wait; per lane the sequence of steps is unchanged.
-      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u; // measured on C3 (tools/compare_vote.sh): 2 -> 3012, 3 -> 2982 Mrays/s
-      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 6u;
+      // Default weights pair : leaf : instance = 2 : 4 : 5, measured (tools/compare_vote.sh, tools/sweep_configs.sh):
+      // against the first choice 1 : 3 : 6 that is +1 % on C3 and +3 .. 9 % on C1 / C2 / C4 / C5.
+      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 2u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 4u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 5u;
       while (true) {
         const uint32_t kind =
             state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;

@@ -2,7 +2,7 @@
 # A/B of vote weights at the bench's own shape (256 spp, 3 timed steps), interleaved repeats.
 set -e
 for rep in 1 2 3; do
-for t in "1 3 6" "1 2 6" "2 5 12"; do
+for t in "1 2 4" "2 4 5" "1 2 3"; do
   set -- $t
   v=$((5 | ($1 << 16) | ($2 << 20) | ($3 << 24)))
   timeout -k 10 300 python -u bench.py --no-cpu-baseline --variant $v 2>/dev/null | python -c "
