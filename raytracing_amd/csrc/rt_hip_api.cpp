@@ -490,10 +490,14 @@ int rt_clear_accum(rt_ctx *ctx) {
 // rare, well-filled regeneration phases (48 idle lanes: Cornell 1280x720 1 spp 1.02 -> 0.58 ms,
 // 64 spp 38.6 -> 36.5 ms); deep trees, whose rays finish far apart, want early ones (16: C3
 // 75 ms vs 84 ms at 48).
-static uint32_t effective_regen_idle(const rt_ctx *ctx) {
+// With many samples per launch the small scenes do better at 32 (tools/sweep_idle.sh, 64 spp, depth 8: C1 7360 ->
+// 7685, C4 2579 -> 2635 Mrays/s).
+static uint32_t effective_regen_idle(const rt_ctx *ctx, const rt_render_params &pc) {
   if (ctx->regen_idle)
     return ctx->regen_idle;
-  return ctx->pair_count <= 16384u ? 48u : 16u;
+  if (ctx->pair_count > 16384u)
+    return 16u;
+  return pc.sqrt_spp * pc.sqrt_spp <= 16u ? 48u : 32u;
 }
 
 int rt_render(rt_ctx *ctx, const rt_render_params *params) {
@@ -551,14 +555,14 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (kind == 7) {
     HIP_TRY(rt_launch_render_v7(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
                                 ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
-                                effective_regen_idle(ctx), ctx->stream));
+                                effective_regen_idle(ctx, pc), ctx->stream));
   } else if (wavefront) {
     rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
     HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
                                        ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->cus, ctx->stream));
   } else {
     HIP_TRY(rt_launch_render(kind == 4 ? 2u : variant, ctx->dev, ctx->camera, pc, ctx->accum,
-                             ctx->counter.ptr, ctx->queue.ptr, effective_regen_idle(ctx), ctx->cus, ctx->stream));
+                             ctx->counter.ptr, ctx->queue.ptr, effective_regen_idle(ctx, pc), ctx->cus, ctx->stream));
   }
   return end_timed(ctx, ev);
 }
