@@ -74,6 +74,7 @@ struct rt_ctx {
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
   DevBuf<uint8_t> cold;   // per-lane path state of k_render_v7 (variant 7), allocated on first use
+  DevBuf<uint8_t> cold10; // per-slot path state + stack spill of k_render_v10 (variant 10), allocated on first use
   uint32_t cus = 0;       // compute units of the device
   DevBuf<uint8_t> wf_mem; // path state of the wavefront pipeline (variant 4)
   uint32_t wf_w = 0, wf_h = 0;
@@ -361,6 +362,7 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->counter.release();
   ctx->queue.release();
   ctx->cold.release();
+  ctx->cold10.release();
   ctx->wf_mem.release();
   ctx->accum_own.release();
   (void)hipStreamDestroy(ctx->stream);
@@ -548,11 +550,22 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       HIP_TRY(ctx->cold.reserve(rt_v7_cold_bytes(ctx->cus)));
     }
   }
+  if (kind == 10) {
+    if (ctx->flat.insts.size() > 0xFFFFu)
+      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel variant 10 packs the instance id into 16 bits");
+    if (!ctx->cold10.ptr) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx->cold10.reserve(rt_v10_cold_bytes(ctx->cus)));
+    }
+  }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  if (kind == 7) {
+  if (kind == 10) {
+    HIP_TRY(rt_launch_render_v10(variant | (ctx->regen_idle << 8), ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
+                                 reinterpret_cast<uint32_t *>(ctx->cold10.ptr), ctx->cus, ctx->stream));
+  } else if (kind == 7) {
     HIP_TRY(rt_launch_render_v7(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
                                 ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
                                 effective_regen_idle(ctx, pc), ctx->stream));
@@ -785,7 +798,7 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
     ctx->variant_auto = true, ctx->variant = 5, ctx->regen_idle = 0;
     return RT_OK;
   }
-  if (!ctx || (variant & 0xFFu) > 7)
+  if (!ctx || (variant & 0xFFu) > 10 || (variant & 0xFFu) == 8 || (variant & 0xFFu) == 9)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   ctx->variant_auto = false;
   // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: per-kernel experiment knobs (rt_kernels.hip)
