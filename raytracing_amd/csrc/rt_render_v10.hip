@@ -3,25 +3,27 @@
 // Measured on the default kernel: the VALU pipe is 67 % busy but only 39 % of the lanes of an issued
 // instruction do useful work — a lane whose path is at a leaf waits while the wave runs a pair step, and so on.  The
 // lever left is lanes per instruction.  Here the paths are decoupled from the lanes: the traversal state of every
-// path (reference, stack pointer, object-space ray, closest t, flags, current instance; a 10-entry stack) lives in
-// LDS, indexed by path slot ([field][slot], 9.75 KB per wave), the path state only shading touches in an HBM block as in
+// path (reference, stack pointer, object-space ray, closest t, flags, current instance; a 12-entry stack) lives in
+// LDS, indexed by path slot ([field][slot], 11 KB per wave), the path state only shading touches in an HBM block as in
 // variant 7.  Every iteration the wave classifies its 128 slots, picks ONE kind of step (pair / leaf triangle /
 // instance entry or exit / shade-and-regenerate), gathers up to 64 slots that wait for that kind — with two
 // candidates per lane a pair step is practically always full — and each lane runs the step for the slot it was
-// handed, reading and writing that slot's state in LDS.  One wave per workgroup, sixteen workgroups per compute unit
-// (156 of the 160 KiB of LDS; 126 VGPRs).
+// handed, reading and writing that slot's state in LDS.  One wave per workgroup, fourteen workgroups per compute
+// unit (154 of the 160 KiB of LDS; 126 VGPRs).
 //
 // Per path the sequence of node visits, triangle tests and RNG draws is exactly that of every other variant: the
 // image is bit-identical.
 //
-// RESULT (C3, 64 spp): 2230 Mrays/s against 2998 for the default kernel.  The pooling works as intended — 27 % fewer
+// RESULT (C3, 64 spp): 2330 Mrays/s against 2950-3000 for the default kernel.  The pooling works as intended — 27 % fewer
 // wave iterations (57 M against 78 M per 16-spp launch), pair steps at 45 instead of 35 active lanes, leaf steps at 29
 // instead of 13, VALU lane utilisation 53 % instead of 39 % (rocprofv3 PMC) — but the bookkeeping costs what it saves:
-// classifying 128 slots, handing them out and moving the slot state through LDS brings an iteration to 192 VALU + 141
-// scalar instructions against 140 + 92, so the wave-level instruction count is unchanged (11.0 G) and the time per
-// instruction slightly worse (16 single-wave workgroups per compute unit, LDS-bound, -DRT_V10_STATS for the counts).
-// Kept as a measured variant (10); what it needs to pay off is a cheaper scheduler (per-kind slot queues maintained
-// incrementally instead of a classification per iteration) and several steps per hand-out.
+// classifying the slots, handing them out and moving the slot state through LDS brings an iteration to 192 VALU + 141
+// scalar instructions against 140 + 92 and adds three LDS round trips to its dependency chain, so the wave-level
+// instruction count is unchanged (11.0 G) and an iteration takes 2.4 us instead of 1.3 us (-DRT_V10_STATS for the
+// counts).  Measured on the way: kind bytes instead of a classification from (state, reference) and bursts of pair
+// steps from registers +4 %; LDS stack of 9 / 11 / 12 / 13 / 15 entries (16 / 15 / 14 / 13 / 10 workgroups per compute
+// unit; 2.7 % ... 0.001 % of the pushes spill to HBM): 2275 / 2284 / 2325 / 2318 / 2078.  Kept as a measured variant
+// (10); what it needs to pay off is a scheduler of a few instructions (per-kind slot queues maintained incrementally).
 #include <stdio.h>
 
 #include "rt_device_inl.h"
@@ -29,7 +31,7 @@
 namespace {
 
 constexpr uint32_t POOL = 128;  // path slots per wave
-constexpr uint32_t NSTK = 10;   // stack entries per slot in LDS; deeper ones in the HBM block
+constexpr uint32_t NSTK = 12;   // stack entries per slot in LDS; deeper ones in the HBM block
 constexpr uint32_t SPILL = RT_MAX_STACK - NSTK;
 
 enum : uint32_t { PS_FETCH = 0, PS_TRAVERSE = 2, PS_SHADE = 3, PS_DONE = 4 };
@@ -37,7 +39,11 @@ enum : uint32_t { PS_FETCH = 0, PS_TRAVERSE = 2, PS_SHADE = 3, PS_DONE = 4 };
 // hot fields, [field][slot] in LDS.  HF_PACK: bits 0-2 state, bit 3 any hit, bit 4 fast slab path allowed,
 // bits 8-15 stack pointer, bits 16-31 current instance (the reference's TLAS holds at most 2^15 instances)
 enum : uint32_t { HF_REF = 0, HF_PACK, HF_CLOSEST, HF_OX, HF_OY, HF_OZ, HF_DX, HF_DY, HF_DZ, HF_COUNT };
-constexpr uint32_t LDS_DWORDS = (HF_COUNT + NSTK) * POOL + 64; // + the compaction list of one step
+// the kind of step a slot waits for, one byte per slot, written by whoever changes the slot (so that the per-iteration
+// classification is one LDS read per slot): 1 pair, 2 instance entry / exit, 3 leaf triangle, 4 shade, 5 needs a
+// pixel, 0 done
+constexpr uint32_t KIND_DWORDS = POOL / 4;
+constexpr uint32_t LDS_DWORDS = (HF_COUNT + NSTK) * POOL + 64 + KIND_DWORDS; // + the compaction list of one step + kinds
 
 // cold fields, [wave][field][slot] in HBM (as in rt_render_v7.hip)
 enum : uint32_t {
@@ -63,11 +69,17 @@ template <int MODE>
 __global__ void __launch_bounds__(64, 4)
     k_render_v10(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, float4 *__restrict__ accum,
                  unsigned long long *ray_counter, uint32_t *__restrict__ queue, uint32_t *__restrict__ cold,
-                 uint32_t regen_min, uint32_t sched_arg) {
+                 uint32_t regen_min, uint32_t sched_arg, uint32_t burst, uint32_t burst_min) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   const lds_ptr hot = (lds_ptr)lds_raw;                          // [HF_COUNT][POOL]
   const lds_ptr stk = (lds_ptr)lds_raw + HF_COUNT * POOL;        // [NSTK][POOL]
   const lds_ptr list = (lds_ptr)lds_raw + (HF_COUNT + NSTK) * POOL; // [64]
+  typedef __attribute__((address_space(3))) uint8_t *lds_u8;
+  const lds_u8 kinds = (lds_u8)((lds_ptr)lds_raw + (HF_COUNT + NSTK) * POOL + 64); // [POOL]
+  auto kind_of = [](uint32_t state, uint32_t ref) -> uint32_t {
+    return state == PS_TRAVERSE ? (!(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u)
+           : state == PS_SHADE ? 4u : state == PS_FETCH ? 5u : 0u;
+  };
   const uint32_t lane = threadIdx.x;
   const uint32_t rows = rt_virtual_rows(pc);
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
@@ -112,8 +124,9 @@ __global__ void __launch_bounds__(64, 4)
   for (uint32_t s = lane; s < POOL; s += 64u) { // every slot starts without a pixel
     HST(HF_PACK, s, PS_FETCH);
     HST(HF_REF, s, RT_REF_NONE);
+    kinds[s] = 5u;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("" ::: "memory"); // LDS operations of one wave execute in order: only the compiler must not reorder
   __builtin_amdgcn_wave_barrier();
 
   uint32_t wave_traced = 0;
@@ -124,10 +137,8 @@ __global__ void __launch_bounds__(64, 4)
     uint32_t kindv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t s = lane + 64u * h;
-      const uint32_t fl = HLD(HF_PACK, s), ref = HLD(HF_REF, s), state = fl & 7u;
-      kindv[h] = state == PS_TRAVERSE ? (!(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u)
-                 : (state == PS_SHADE || (state == PS_FETCH && !queue_dry)) ? 4u : 0u;
+      const uint32_t k = kinds[lane + 64u * h];
+      kindv[h] = k == 5u ? (queue_dry ? 0u : 4u) : k;
     }
     uint32_t cnt[5];
 #pragma unroll
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(64, 4)
     const unsigned long long below = (1ull << lane) - 1ull;
     if (second)
       list[__popcll(m_second & below)] = lane + 64u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory"); // LDS operations of one wave execute in order: only the compiler must not reorder
     __builtin_amdgcn_wave_barrier();
     const uint32_t free_rank = (uint32_t)__popcll(~m_own & below);
     const bool take = !own && free_rank < (uint32_t)__popcll(m_second);
@@ -168,48 +179,63 @@ __global__ void __launch_bounds__(64, 4)
 #endif
 
     if (K == 1u) {
-      if (active) { // interior pair: both child boxes, near child next, far child pushed
-        uint32_t ref = HLD(HF_REF, slot), fl = HLD(HF_PACK, slot);
-        uint32_t sp = (fl >> 8) & 0xFFu;
-        const V3 co = v3(HLDF(HF_OX, slot), HLDF(HF_OY, slot), HLDF(HF_OZ, slot));
-        const V3 cd = v3(HLDF(HF_DX, slot), HLDF(HF_DY, slot), HLDF(HF_DZ, slot));
+      // interior pair: both child boxes, near child next, far child pushed.  A burst: the lanes whose slot is at a pair
+      // again afterwards repeat the step from registers (no hand-out, no LDS round trip) while enough of them remain.
+      uint32_t ref = 0, fl = 0, sp = 0;
+      V3 co = v3(0.f, 0.f, 0.f), cd = co, cinv = co;
+      float closest = 0.f;
+      if (active) {
+        ref = HLD(HF_REF, slot), fl = HLD(HF_PACK, slot);
+        sp = (fl >> 8) & 0xFFu;
+        co = v3(HLDF(HF_OX, slot), HLDF(HF_OY, slot), HLDF(HF_OZ, slot));
+        cd = v3(HLDF(HF_DX, slot), HLDF(HF_DY, slot), HLDF(HF_DZ, slot));
         // the reciprocals of the ray space are recomputed (3 instructions an axis) rather than kept in LDS
-        const V3 cinv = MODE == RT_AABB_RCP ? inv_direction(cd)
-                                            : v3(refined_rcp(cd.x), refined_rcp(cd.y), refined_rcp(cd.z));
-        const float closest = HLDF(HF_CLOSEST, slot);
-        const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-        const float4 qx = q[0], qy = q[1], qz = q[2];
-        const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
-        float dist1, dist2;
-        if (fl & 16u) {
-          slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
-        } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
-          float4 lo0, hi0, lo1, hi1;
-          unpack_pair(qx, qy, qz, make_float4(r2.x, r2.y, 0.f, 0.f), lo0, hi0, lo1, hi1);
-          dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-          dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+        cinv = MODE == RT_AABB_RCP ? inv_direction(cd) : v3(refined_rcp(cd.x), refined_rcp(cd.y), refined_rcp(cd.z));
+        closest = HLDF(HF_CLOSEST, slot);
+      }
+      bool want = active;
+      for (uint32_t b = 0;; ++b) {
+        if (want) {
+          const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
+          const float4 qx = q[0], qy = q[1], qz = q[2];
+          const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
+          float dist1, dist2;
+          if (fl & 16u) {
+            slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
+          } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
+            float4 lo0, hi0, lo1, hi1;
+            unpack_pair(qx, qy, qz, make_float4(r2.x, r2.y, 0.f, 0.f), lo0, hi0, lo1, hi1);
+            dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+            dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+          }
+          uint32_t c1 = __float_as_uint(r2.x), c2 = __float_as_uint(r2.y);
+          if (dist1 > dist2) {
+            float tf = dist1;
+            dist1 = dist2;
+            dist2 = tf;
+            uint32_t tc = c1;
+            c1 = c2;
+            c2 = tc;
+          }
+          if (dist1 == kMiss) {
+            if (sp == 0u)
+              fl = (fl & ~7u) | PS_SHADE;
+            else
+              ref = pop(slot, sp);
+          } else {
+            if (dist2 != kMiss)
+              push(slot, sp, c2);
+            ref = c1;
+          }
+          want = (fl & 7u) == PS_TRAVERSE && !(ref & RT_REF_LEAF);
         }
-        uint32_t c1 = __float_as_uint(r2.x), c2 = __float_as_uint(r2.y);
-        if (dist1 > dist2) {
-          float tf = dist1;
-          dist1 = dist2;
-          dist2 = tf;
-          uint32_t tc = c1;
-          c1 = c2;
-          c2 = tc;
-        }
-        if (dist1 == kMiss) {
-          if (sp == 0u)
-            fl = (fl & ~7u) | PS_SHADE;
-          else
-            ref = pop(slot, sp);
-        } else {
-          if (dist2 != kMiss)
-            push(slot, sp, c2);
-          ref = c1;
-        }
+        if (b + 1u >= burst || (uint32_t)__popcll(__ballot(want)) < burst_min)
+          break;
+      }
+      if (active) {
         HST(HF_REF, slot, ref);
         HST(HF_PACK, slot, (fl & 0xFFFF00FFu) | (sp << 8));
+        kinds[slot] = (uint8_t)kind_of(fl & 7u, ref);
       }
     } else if (K == 3u) {
       if (active) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
@@ -252,6 +278,7 @@ __global__ void __launch_bounds__(64, 4)
         }
         HST(HF_REF, slot, ref);
         HST(HF_PACK, slot, (fl & 0xFFFF00FFu) | (sp << 8));
+        kinds[slot] = (uint8_t)kind_of(fl & 7u, ref);
       }
     } else if (K == 2u) {
       if (active) { // change of ray space: enter an instance, or (sentinel) return to world space
@@ -283,6 +310,7 @@ __global__ void __launch_bounds__(64, 4)
         HSTF(HF_DX, slot, cd.x), HSTF(HF_DY, slot, cd.y), HSTF(HF_DZ, slot, cd.z);
         HST(HF_REF, slot, ref);
         HST(HF_PACK, slot, (fl & 0xFFFF00FFu) | (sp << 8));
+        kinds[slot] = (uint8_t)kind_of(fl & 7u, ref);
       }
     } else {
       // ===== regeneration: slots whose ray is finished, or that have no pixel =====
@@ -395,6 +423,7 @@ __global__ void __launch_bounds__(64, 4)
         HSTF(HF_OX, slot, co.x), HSTF(HF_OY, slot, co.y), HSTF(HF_OZ, slot, co.z);
         HSTF(HF_DX, slot, cd.x), HSTF(HF_DY, slot, cd.y), HSTF(HF_DZ, slot, cd.z);
         HST(HF_PACK, slot, (ref == RT_REF_NONE ? PS_SHADE : PS_TRAVERSE) | (fast ? 16u : 0u)); // sp 0, instance 0
+        kinds[slot] = (uint8_t)kind_of(ref == RT_REF_NONE ? PS_SHADE : PS_TRAVERSE, ref);
         CST_F(CF_OX, slot, p.o.x), CST_F(CF_OY, slot, p.o.y), CST_F(CF_OZ, slot, p.o.z);
         CST_F(CF_DX, slot, p.d.x), CST_F(CF_DY, slot, p.d.y), CST_F(CF_DZ, slot, p.d.z);
         CST_F(CF_AX, slot, p.attenuation.x), CST_F(CF_AY, slot, p.attenuation.y), CST_F(CF_AZ, slot, p.attenuation.z);
@@ -406,11 +435,12 @@ __global__ void __launch_bounds__(64, 4)
         CST_U(CF_DEPTH, slot, depth);
       } else if (active) {
         HST(HF_PACK, slot, state == PS_DONE ? PS_DONE : PS_FETCH); // no pixel (yet), or none left
+        kinds[slot] = state == PS_DONE ? 0u : 5u;
       }
     }
     // the next classification reads what this step wrote (other lanes' slots): LDS operations of one wave execute in
     // order, the fence keeps the compiler from moving them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory"); // LDS operations of one wave execute in order: only the compiler must not reorder
     __builtin_amdgcn_wave_barrier();
   }
   count_rays(ray_counter, wave_traced);
@@ -424,7 +454,7 @@ __global__ void __launch_bounds__(64, 4)
 #undef CST_F
 }
 
-constexpr uint32_t WAVES_PER_CU = 16; // LDS: 16 x 9,984 B = 156 KiB of the 160 KiB
+constexpr uint32_t WAVES_PER_CU = 14; // LDS bound: 14 x 11,264 B
 size_t rt_v10_cold_bytes(uint32_t cus) { return (size_t)cus * WAVES_PER_CU * COLD_DWORDS_PER_WAVE * sizeof(uint32_t); }
 
 hipError_t rt_launch_render_v10(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
@@ -435,6 +465,8 @@ hipError_t rt_launch_render_v10(uint32_t variant, const rt_dev_scene &sc, const 
   if (pc.image_width > 0xFFFFu || pc.image_height > 0xFFFFu)
     return hipErrorInvalidValue; // pixel coordinates are packed 16:16 in the cold block
   const uint32_t sched = ((variant >> 16) & 0xFFFu) | ((variant >> 31) ? 0x8000u : 0u);
+  const uint32_t burst = ((variant >> 28) & 7u) ? ((variant >> 28) & 7u) : 2u; // pair steps per hand-out (1 / 2 / 3 / 6: 2199 / 2275 / 2259 / 2273)
+  const uint32_t burst_min = 24u;                                               // ... while this many lanes go on
   uint32_t regen_min = (variant >> 8) & 0xFFu;
   if (regen_min == 0 || regen_min > POOL)
     regen_min = 48u; // measured: 16 / 32 / 48 / 64 -> 1984 / 2132 / 2212 / 2180 Mrays/s
@@ -449,10 +481,10 @@ hipError_t rt_launch_render_v10(uint32_t variant, const rt_dev_scene &sc, const 
   const size_t lds = LDS_DWORDS * sizeof(uint32_t);
   if (pc.aabb_mode == RT_AABB_RCP)
     hipLaunchKernelGGL((k_render_v10<RT_AABB_RCP>), dim3(blocks), dim3(64), lds, stream, sc, cam, pc, acc, d_counter,
-                       d_queue, d_cold, regen_min, sched);
+                       d_queue, d_cold, regen_min, sched, burst, burst_min);
   else
     hipLaunchKernelGGL((k_render_v10<RT_AABB_DIV>), dim3(blocks), dim3(64), lds, stream, sc, cam, pc, acc, d_counter,
-                       d_queue, d_cold, regen_min, sched);
+                       d_queue, d_cold, regen_min, sched, burst, burst_min);
 #ifdef RT_V10_STATS
   {
     unsigned long long h[16], z[16] = {0};
