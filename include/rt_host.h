@@ -61,6 +61,8 @@ rt_material_handle rth_add_lambert_texture(rth_renderer *r, int32_t width, int32
 rt_material_handle rth_add_lambert_image(rth_renderer *r, const char *file_path);
 /* the decoder alone: fills *width / *height and, if rgba8 != NULL and capacity >= w*h*4, the pixels; returns 0 or
  * -1 with a message in err */
+/* the command line's PNG writer (8-bit RGB, rows top to bottom); 0 or -1 */
+int rth_write_png_rgb8(const char *file_path, uint32_t width, uint32_t height, const uint8_t *rgb8);
 int rth_decode_image(const char *file_path, uint32_t *width, uint32_t *height, uint8_t *rgba8, uint64_t capacity,
                      char *err, size_t err_len);
 rt_material_handle rth_add_metal_material(rth_renderer *r, const float *albedo_rgb, float fuzz);

@@ -138,6 +138,9 @@ rt_material_handle rth_add_lambert_texture(rth_renderer *r, int32_t w, int32_t h
 rt_material_handle rth_add_lambert_image(rth_renderer *r, const char *file_path) {
   return r && file_path ? r->r.add_lambert_material(std::string(file_path)) : kNoMaterial;
 }
+int rth_write_png_rgb8(const char *file_path, uint32_t width, uint32_t height, const uint8_t *rgb8) {
+  return file_path && rta::write_png_rgb8(file_path, width, height, rgb8) ? 0 : -1;
+}
 int rth_decode_image(const char *file_path, uint32_t *width, uint32_t *height, uint8_t *rgba8, uint64_t capacity,
                      char *err, size_t err_len) {
   rta::Image img;

@@ -23,83 +23,11 @@
 #include <string>
 #include <vector>
 
+#include "image_decode.h"
 #include "renderer.h"
 #include "scene_file.h"
 
 namespace {
-
-// ---- PNG (RGB8, zlib "stored" blocks: no compressor needed) -----------------
-uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
-  static uint32_t table[256];
-  static bool ready = false;
-  if (!ready) {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k)
-        c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-      table[i] = c;
-    }
-    ready = true;
-  }
-  for (size_t i = 0; i < n; ++i)
-    crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
-  return crc;
-}
-
-void put_be32(std::vector<uint8_t> &v, uint32_t x) {
-  v.push_back((uint8_t)(x >> 24)), v.push_back((uint8_t)(x >> 16)), v.push_back((uint8_t)(x >> 8)),
-      v.push_back((uint8_t)x);
-}
-
-void chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data) {
-  put_be32(png, (uint32_t)data.size());
-  size_t start = png.size();
-  png.insert(png.end(), type, type + 4);
-  png.insert(png.end(), data.begin(), data.end());
-  uint32_t crc = crc32_update(0xFFFFFFFFu, png.data() + start, png.size() - start) ^ 0xFFFFFFFFu;
-  put_be32(png, crc);
-}
-
-bool write_png_rgb8(const std::string &path, uint32_t w, uint32_t h, const std::vector<uint8_t> &rgb) {
-  std::vector<uint8_t> raw; // scanlines, filter byte 0 each
-  raw.reserve((size_t)h * (3 * w + 1));
-  for (uint32_t y = 0; y < h; ++y) {
-    raw.push_back(0);
-    raw.insert(raw.end(), rgb.begin() + (size_t)y * w * 3, rgb.begin() + (size_t)(y + 1) * w * 3);
-  }
-  std::vector<uint8_t> z;
-  z.push_back(0x78), z.push_back(0x01); // zlib header, no compression
-  uint32_t a = 1, b = 0;                // adler32
-  size_t pos = 0;
-  do {
-    size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
-    bool last = pos + n == raw.size();
-    z.push_back(last ? 1 : 0);
-    z.push_back((uint8_t)(n & 0xFF)), z.push_back((uint8_t)(n >> 8));
-    z.push_back((uint8_t)(~n & 0xFF)), z.push_back((uint8_t)((~n >> 8) & 0xFF));
-    for (size_t i = 0; i < n; ++i) {
-      a = (a + raw[pos + i]) % 65521u;
-      b = (b + a) % 65521u;
-    }
-    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
-    pos += n;
-  } while (pos < raw.size());
-  put_be32(z, (b << 16) | a);
-
-  std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  std::vector<uint8_t> ihdr;
-  put_be32(ihdr, w), put_be32(ihdr, h);
-  ihdr.push_back(8), ihdr.push_back(2), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);
-  chunk(png, "IHDR", ihdr);
-  chunk(png, "IDAT", z);
-  chunk(png, "IEND", {});
-  FILE *f = fopen(path.c_str(), "wb");
-  if (!f)
-    return false;
-  bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
-  ok = fclose(f) == 0 && ok;
-  return ok;
-}
 
 // fragMain + agxToneMap, FullScreen.slang:38-55; byte conversion as Image.hpp:62-66
 uint8_t tone_map_byte(float c) {
@@ -223,7 +151,7 @@ int main(int argc, char **argv) {
   for (size_t p = 0; p < (size_t)scene.screen_width * scene.screen_height; ++p)
     for (int c = 0; c < 3; ++c)
       rgb[p * 3 + c] = tone_map_byte(img[p * 4 + c]);
-  if (!write_png_rgb8(out_png, scene.screen_width, scene.screen_height, rgb)) {
+  if (!rta::write_png_rgb8(out_png, scene.screen_width, scene.screen_height, rgb.data())) {
     fprintf(stderr, "error: cannot write %s\n", out_png.c_str());
     return 1;
   }

@@ -18,5 +18,8 @@ struct Image {
 bool decode_image_rgba8(const std::vector<uint8_t> &file_bytes, Image &out, std::string &err);
 bool load_image_rgba8(const std::string &path, Image &out, std::string &err);
 
+// 8-bit RGB PNG (image_encode.cpp): rgb = width * height * 3 bytes, rows top to bottom
+bool write_png_rgb8(const std::string &path, uint32_t width, uint32_t height, const uint8_t *rgb);
+
 } // namespace rta
 #endif

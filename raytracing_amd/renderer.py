@@ -25,7 +25,7 @@ PLANE, CUBE, SPHERE = 0, 1, 2
 HOST_SYMBOLS = [
     "rth_create", "rth_destroy", "rth_resize", "rth_render", "rth_set_option", "rth_get_frame_index",
     "rth_reset_accumulation", "rth_add_lambert_material", "rth_add_lambert_texture", "rth_add_lambert_image",
-    "rth_decode_image", "rth_import_gltf",
+    "rth_decode_image", "rth_write_png_rgb8", "rth_import_gltf",
     "rth_add_metal_material", "rth_add_dielectric_material", "rth_add_emissive_material",
     "rth_remove_material", "rth_default_material", "rth_add_blas", "rth_add_blas_mesh",
     "rth_add_blas_instance", "rth_set_blas_instance_transform", "rth_remove_blas",
@@ -74,6 +74,7 @@ def lib():
     L.rth_add_lambert_image.argtypes = [vp, C.c_char_p]; L.rth_add_lambert_image.restype = MH
     L.rth_decode_image.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp, C.c_uint64, C.c_char_p, C.c_size_t]
     L.rth_decode_image.restype = C.c_int
+    L.rth_write_png_rgb8.argtypes = [C.c_char_p, u32, u32, vp]; L.rth_write_png_rgb8.restype = C.c_int
     L.rth_import_gltf.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, C.c_size_t]; L.rth_import_gltf.restype = C.c_int64
     L.rth_add_metal_material.argtypes = [vp, vp, f32]; L.rth_add_metal_material.restype = MH
     L.rth_add_dielectric_material.argtypes = [vp, f32]; L.rth_add_dielectric_material.restype = MH
@@ -137,6 +138,13 @@ def decode_image(path):
     if lib().rth_decode_image(os.fsencode(path), C.byref(w), C.byref(h), T.ptr(px), px.size, err, len(err)) != 0:
         raise RendererError(err.value.decode(errors="replace"))
     return px
+
+
+def write_png_rgb8(path, rgb):
+    """The command line's PNG writer: uint8 array [h, w, 3]."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    if lib().rth_write_png_rgb8(os.fsencode(path), rgb.shape[1], rgb.shape[0], T.ptr(rgb)) != 0:
+        raise RendererError("cannot write " + str(path))
 
 
 class Mesh:

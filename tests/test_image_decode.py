@@ -222,6 +222,30 @@ def test_png_files_of_the_reference_repository(name):
     assert np.array_equal(R.decode_image(path), np.asarray(PIL.open(path).convert("RGBA")))
 
 
+def test_png_writer_round_trips(tmp_path):
+    """The command line's PNG writer (image_encode.cpp: row filters + fixed-Huffman DEFLATE with LZ77 matches):
+    Pillow and the product's decoder read back the pixels that were written; smooth images shrink."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:90, 0:160]
+    images = {
+        "noise": rng.integers(0, 256, (37, 53, 3), dtype=np.uint8),
+        "gradient": np.stack([xx * 255 // 159, yy * 255 // 89, (xx + yy) % 256], -1).astype(np.uint8),
+        "flat": np.full((64, 64, 3), 200, np.uint8),
+        "tiles": np.tile(rng.integers(0, 256, (8, 8, 3), dtype=np.uint8), (20, 30, 1)),
+        "one": rng.integers(0, 256, (1, 1, 3), dtype=np.uint8),
+        "row": rng.integers(0, 256, (1, 300, 3), dtype=np.uint8),
+    }
+    for name, img in images.items():
+        path = str(tmp_path / (name + ".png"))
+        R.write_png_rgb8(path, img)
+        assert np.array_equal(np.asarray(PIL.open(path).convert("RGB")), img), name
+        assert np.array_equal(R.decode_image(path)[..., :3], img), name
+        PIL.open(path).verify()
+    for name in ("gradient", "flat", "tiles"):
+        assert os.path.getsize(tmp_path / (name + ".png")) < images[name].size // 4, name
+
+
 def test_pnm(tmp_path):
     rng = np.random.default_rng(5)
     g = rng.integers(0, 256, (6, 9), dtype=np.uint8)

@@ -139,23 +139,11 @@ def test_cli_refuses_other_renderers_and_bad_usage():
 
 
 def _read_png_rgb8(path):
-    data = open(path, "rb").read()
-    assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, w = 8, b"", None
-    while pos < len(data):
-        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
-        body = data[pos + 8:pos + 8 + n]
-        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
-        assert crc == (zlib.crc32(typ + body) & 0xFFFFFFFF), typ
-        if typ == b"IHDR":
-            w, h, depth, colour, comp, flt, inter = struct.unpack(">IIBBBBB", body)
-            assert (depth, colour, comp, flt, inter) == (8, 2, 0, 0, 0)
-        elif typ == b"IDAT":
-            idat += body
-        pos += 12 + n
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
-    assert (raw[:, 0] == 0).all()
-    return raw[:, 1:].reshape(h, w, 3)
+    """Decoded by Pillow (independent of the product) and by the product's own decoder: both must agree."""
+    from PIL import Image
+    img = np.asarray(Image.open(path).convert("RGB"))
+    assert np.array_equal(img, R.decode_image(path)[..., :3])
+    return img
 
 
 def _tone_map(img):  # FullScreen.slang:38-55 + Image.hpp:62-66
