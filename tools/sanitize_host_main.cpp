@@ -1,6 +1,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include "image_decode.h"
 #include "gltf_file.h"
 #include "renderer.h"
@@ -12,7 +13,28 @@ int main(int argc, char **argv) {
     std::string p = argv[i], err;
     if (p.size() > 4 && (p.substr(p.size() - 4) == ".png" || p.substr(p.size() - 4) == ".pgm")) {
       rta::Image img;
-      (rta::load_image_rgba8(p, img, err) ? ok : bad)++;
+      if (rta::load_image_rgba8(p, img, err)) {
+        ++ok;
+        // the PNG writer on what was decoded, read back by the decoder
+        std::vector<uint8_t> rgb((size_t)img.width * img.height * 3);
+        for (size_t k = 0; k < (size_t)img.width * img.height; ++k)
+          memcpy(&rgb[3 * k], &img.rgba[4 * k], 3);
+        const std::string tmp = p + ".rewritten.png";
+        rta::Image back;
+        if (!rta::write_png_rgb8(tmp, img.width, img.height, rgb.data()) || !rta::load_image_rgba8(tmp, back, err) ||
+            back.width != img.width || back.height != img.height) {
+          fprintf(stderr, "PNG writer round trip failed for %s\n", p.c_str());
+          return 3;
+        }
+        for (size_t k = 0; k < (size_t)img.width * img.height; ++k)
+          if (memcmp(&back.rgba[4 * k], &rgb[3 * k], 3) != 0) {
+            fprintf(stderr, "PNG writer round trip differs for %s\n", p.c_str());
+            return 3;
+          }
+        remove(tmp.c_str());
+      } else {
+        ++bad;
+      }
     } else if (p.size() > 4 && p.substr(p.size() - 4) == ".obj") {
       rta::ObjModel m;
       (rta::load_obj(p, m, err) ? ok : bad)++;
