@@ -5,6 +5,12 @@
 // reference so the resulting bits are identical.
 #include "accel_build.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "hmath.h"
@@ -129,46 +135,57 @@ struct Builder {
   // subdivide, BVHNode.cpp:107-161, over an explicit stack.  Children are
   // numbered when their parent splits and the left subtree is finished before
   // the right one starts, exactly as the recursion numbers them.
+  // One subdivision step (BVHNode.cpp:107-161): splits node n into nodes_count, nodes_count + 1 and returns true, or
+  // leaves it a leaf.
+  bool split_once(uint32_t n) {
+    rt_bvh_node &node = nodes[n];
+    int axis = -1;
+    float pos = 0.f;
+    const float best = best_split(node, axis, pos);
+    vec3 e = vec3(node.aabb_max) - vec3(node.aabb_min);
+    const float parent_area = e.x * e.y + e.y * e.z + e.z * e.x;
+    const float parent_cost = node.tri_count * parent_area;
+    if (best >= parent_cost)
+      return false;
+    // partition (BVHNode.cpp:128-136); signed 64-bit so that first == 0 is safe
+    int64_t l = node.local_left_first;
+    int64_t r = l + node.tri_count - 1;
+    while (l <= r) {
+      if (centroids[3 * (size_t)ids[l] + axis] < pos) {
+        ++l;
+      } else {
+        uint32_t t = ids[l];
+        ids[l] = ids[r];
+        ids[r] = t;
+        --r;
+      }
+    }
+    const uint32_t left_count = (uint32_t)(l - node.local_left_first);
+    if (left_count == 0 || left_count == node.tri_count)
+      return false;
+    const uint32_t li = nodes_count++, ri = nodes_count++;
+    nodes[li].local_left_first = node.local_left_first;
+    nodes[li].tri_count = left_count;
+    nodes[ri].local_left_first = (uint32_t)l;
+    nodes[ri].tri_count = node.tri_count - left_count;
+    node.local_left_first = li;
+    node.tri_count = 0;
+    fit(li);
+    fit(ri);
+    return true;
+  }
+
+  // subdivide over an explicit stack.  Children are numbered when their parent splits and the left subtree is
+  // finished before the right one starts, exactly as the recursion numbers them.
   void run() {
     std::vector<uint32_t> todo{0};
     while (!todo.empty()) {
       const uint32_t n = todo.back();
       todo.pop_back();
-      rt_bvh_node &node = nodes[n];
-      int axis = -1;
-      float pos = 0.f;
-      const float best = best_split(node, axis, pos);
-      vec3 e = vec3(node.aabb_max) - vec3(node.aabb_min);
-      const float parent_area = e.x * e.y + e.y * e.z + e.z * e.x;
-      const float parent_cost = node.tri_count * parent_area;
-      if (best >= parent_cost)
+      if (!split_once(n))
         continue;
-      // partition (BVHNode.cpp:128-136); signed 64-bit so that first == 0 is safe
-      int64_t l = node.local_left_first;
-      int64_t r = l + node.tri_count - 1;
-      while (l <= r) {
-        if (centroids[3 * (size_t)ids[l] + axis] < pos) {
-          ++l;
-        } else {
-          uint32_t t = ids[l];
-          ids[l] = ids[r];
-          ids[r] = t;
-          --r;
-        }
-      }
-      const uint32_t left_count = (uint32_t)(l - node.local_left_first);
-      if (left_count == 0 || left_count == node.tri_count)
-        continue;
-      const uint32_t li = nodes_count++, ri = nodes_count++;
-      nodes[li].local_left_first = node.local_left_first;
-      nodes[li].tri_count = left_count;
-      nodes[ri].local_left_first = (uint32_t)l;
-      nodes[ri].tri_count = node.tri_count - left_count;
-      node.local_left_first = li;
-      node.tri_count = 0;
-      fit(li);
-      fit(ri);
-      todo.push_back(ri);
+      const uint32_t li = nodes[n].local_left_first;
+      todo.push_back(li + 1);
       todo.push_back(li);
     }
   }
@@ -176,8 +193,146 @@ struct Builder {
 
 } // namespace
 
+namespace {
+
+// ---- the same build on several host threads -----------------------------------------------------------------------
+// The reference's recursion (BVHNode.cpp:107-161) numbers the two children of a node when it splits and finishes the
+// left subtree before the right one.  Subtrees work on disjoint ranges of the triangle-id array, so they can be built
+// independently: the top of the tree is split on one thread down to subtrees of at most `grain` triangles, every such
+// subtree is built by a Builder of its own into a private node array (numbered from its own root), and a final
+// depth-first pass over the top hands out the node numbers in the reference's order and copies the subtrees to their
+// places.  Every box, split and leaf is the one the single-threaded build produces.
+struct TopNode {
+  uint32_t first = 0, count = 0;
+  float lo[3], hi[3];
+  int left = -1, right = -1; // children in `top` when the node was split on the main thread
+  int task = -1;             // subtree built by a worker
+};
+
+uint32_t build_blas_parallel(rt_bvh_node *nodes, const rt_triangle_geom *tris, const float *centroids,
+                             uint32_t *tri_ids, uint32_t tri_count, uint32_t first, unsigned threads) {
+  const uint32_t grain = std::max<uint32_t>(4096u, tri_count / (threads * 8u));
+  std::vector<TopNode> top;
+  std::vector<int> tasks; // indices into top
+  {
+    Builder b; // main-thread splitter: node 0 of a two-node scratch is the node being split
+    rt_bvh_node scratch[3];
+    b.nodes = scratch, b.tris = tris, b.centroids = centroids, b.ids = tri_ids;
+    scratch[0].local_left_first = first, scratch[0].tri_count = tri_count;
+    b.fit(0);
+    TopNode root;
+    root.first = first, root.count = tri_count;
+    memcpy(root.lo, scratch[0].aabb_min, 12), memcpy(root.hi, scratch[0].aabb_max, 12);
+    top.push_back(root);
+    std::vector<int> todo{0};
+    while (!todo.empty()) {
+      const int t = todo.back();
+      todo.pop_back();
+      if (top[(size_t)t].count <= grain) {
+        top[(size_t)t].task = (int)tasks.size();
+        tasks.push_back(t);
+        continue;
+      }
+      // one step of Builder::run on this node
+      scratch[0].local_left_first = top[(size_t)t].first, scratch[0].tri_count = top[(size_t)t].count;
+      memcpy(scratch[0].aabb_min, top[(size_t)t].lo, 12), memcpy(scratch[0].aabb_max, top[(size_t)t].hi, 12);
+      b.nodes_count = 1;
+      if (!b.split_once(0))
+        continue; // stays a leaf
+      TopNode l, r;
+      l.first = scratch[1].local_left_first, l.count = scratch[1].tri_count;
+      memcpy(l.lo, scratch[1].aabb_min, 12), memcpy(l.hi, scratch[1].aabb_max, 12);
+      r.first = scratch[2].local_left_first, r.count = scratch[2].tri_count;
+      memcpy(r.lo, scratch[2].aabb_min, 12), memcpy(r.hi, scratch[2].aabb_max, 12);
+      const int li = (int)top.size();
+      top.push_back(l), top.push_back(r);
+      top[(size_t)t].left = li, top[(size_t)t].right = li + 1;
+      todo.push_back(li + 1), todo.push_back(li);
+    }
+  }
+  // workers: largest subtrees first
+  std::vector<std::vector<rt_bvh_node>> built(tasks.size());
+  std::vector<uint32_t> built_count(tasks.size(), 0);
+  std::vector<size_t> order(tasks.size());
+  for (size_t i = 0; i < order.size(); ++i)
+    order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t c) {
+    return top[(size_t)tasks[a]].count > top[(size_t)tasks[c]].count;
+  });
+  std::atomic<size_t> next_task{0};
+  auto work = [&]() {
+    for (;;) {
+      const size_t k = next_task.fetch_add(1);
+      if (k >= order.size())
+        return;
+      const size_t ti = order[k];
+      const TopNode &t = top[(size_t)tasks[ti]];
+      std::vector<rt_bvh_node> &local = built[ti];
+      local.assign((size_t)t.count * 2 - 1, rt_bvh_node{});
+      Builder b;
+      b.nodes = local.data(), b.tris = tris, b.centroids = centroids, b.ids = tri_ids;
+      local[0].local_left_first = t.first, local[0].tri_count = t.count;
+      memcpy(local[0].aabb_min, t.lo, 12), memcpy(local[0].aabb_max, t.hi, 12);
+      b.run();
+      built_count[ti] = b.nodes_count;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned i = 1; i < threads; ++i)
+    pool.emplace_back(work);
+  work();
+  for (std::thread &th : pool)
+    th.join();
+  // numbering pass: depth first, children numbered at the split, left subtree before right
+  uint32_t next = 1;
+  struct Item {
+    int t;
+    uint32_t id;
+  };
+  std::vector<Item> stack{{0, 0u}};
+  while (!stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    const TopNode &t = top[(size_t)it.t];
+    rt_bvh_node &out = nodes[it.id];
+    memcpy(out.aabb_min, t.lo, 12), memcpy(out.aabb_max, t.hi, 12);
+    if (t.task >= 0) {
+      const std::vector<rt_bvh_node> &local = built[(size_t)t.task];
+      const uint32_t n_local = built_count[(size_t)t.task], base = next;
+      auto place = [&](uint32_t k) -> rt_bvh_node & { return k == 0 ? nodes[it.id] : nodes[base + k - 1]; };
+      for (uint32_t k = 0; k < n_local; ++k) {
+        rt_bvh_node v = local[k];
+        if (v.tri_count == 0)
+          v.local_left_first = base + v.local_left_first - 1; // child index: local -> global
+        place(k) = v;
+      }
+      next += n_local - 1;
+    } else if (t.left >= 0) {
+      const uint32_t li = next++, ri = next++;
+      out.local_left_first = li, out.tri_count = 0;
+      stack.push_back({t.right, ri});
+      stack.push_back({t.left, li});
+    } else {
+      out.local_left_first = t.first, out.tri_count = t.count;
+    }
+  }
+  return next;
+}
+
+} // namespace
+
 uint32_t build_blas(rt_bvh_node *nodes, const rt_triangle_geom *tris, const float *centroids,
                     uint32_t *tri_ids, uint32_t tri_count, uint32_t first) {
+  // large meshes on several threads (same nodes, same triangle order); RTA_BUILD_THREADS=1 forces one
+  unsigned threads = std::thread::hardware_concurrency();
+  threads = threads > 16u ? 16u : (threads ? threads : 1u);
+  if (const char *env = getenv("RTA_BUILD_THREADS")) {
+    const long v = atol(env);
+    if (v >= 1 && v <= 64)
+      threads = (unsigned)v;
+  }
+  if (threads > 1 && tri_count >= 32768u)
+    return build_blas_parallel(nodes, tris, centroids, tri_ids, tri_count, first, threads);
   Builder b;
   b.nodes = nodes, b.tris = tris, b.centroids = centroids, b.ids = tri_ids;
   nodes[0].local_left_first = first;

@@ -104,6 +104,27 @@ def test_blas_refit_equals_oracle_and_bounds_the_moved_triangles():
                 assert (c["aabb_min"] >= nd["aabb_min"]).all() and (c["aabb_max"] <= nd["aabb_max"]).all()
 
 
+def test_parallel_blas_build_equals_the_sequential_one_and_the_oracle(monkeypatch):
+    """Meshes of 32 K triangles and more are built on several host threads (subtrees in parallel, node numbers handed
+    out in the reference's depth-first order afterwards): nodes and triangle order equal the single-threaded build and
+    the oracle's, bit for bit, for several thread counts."""
+    mesh = R.Mesh.dragon(240, 96, 7)  # 46,080 triangles
+    o = O.OracleRenderer()
+    o.add_blas(*mesh.arrays())
+    n = len(o.tri_ids)
+    assert n >= 32768
+    want_count = int(o.blas[0]["nodes_count"])
+    for threads in ("1", "2", "5", "8"):
+        monkeypatch.setenv("RTA_BUILD_THREADS", threads)
+        geom, cent = o.geom.copy(), o.centroids.copy()
+        ids = np.arange(n, dtype=np.uint32)
+        nodes = np.zeros(2 * n - 1, T.bvh_node_dtype)
+        count = R.lib().rth_build_blas(T.ptr(nodes), T.ptr(geom), T.ptr(cent), T.ptr(ids), n, 0)
+        assert count == want_count, threads
+        _same_struct(nodes[:count], o.nodes[:count])
+        assert np.array_equal(ids, o.tri_ids), threads
+
+
 def test_blas_builder_nonzero_offset():
     # a second BLAS lives at a non-zero tri-id offset: leaf indices are global
     o = O.OracleRenderer()
