@@ -78,6 +78,9 @@ def main():
                     help="N>1: progressive frames round-robin + reduce (default), contiguous row bands + all-gather, "
                          "or interleaved 8-row groups + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 on a box with fewer GPUs than ranks: ranks share the GPUs (local_rank %% device_count) and "
+                         "talk over gloo instead of RCCL.  Exercises the multi-rank code path; its numbers mean nothing.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -98,10 +101,15 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
     sqrt_spp = int(round(args.spp ** 0.5))
@@ -170,7 +178,8 @@ def main():
     st = _ffi.Stats()
     _ffi._check(L.rt_get_stats(ctx, C.byref(st)))
     rays_local = float(st.rays_traced)
-    vals = torch.tensor([elapsed, rays_local, st.total_kernel_ms], dtype=torch.float64, device="cuda")
+    vals = torch.tensor([elapsed, rays_local, st.total_kernel_ms], dtype=torch.float64,
+                        device="cpu" if args.rehearse else "cuda")
     if world > 1:
         tmax = vals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -251,7 +260,7 @@ def main():
         "metric": "Mrays/s (incl. bounces) dragon scene", "value": value, "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (bands is not None or interleave is not None) else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL: shared GPU, gloo)",
         "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)", "triangles": n_tris,
                    "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
                    "rng": "wang", "aabb": args.aabb, "kernel_variant": args.variant,
