@@ -60,7 +60,8 @@ def algorithmic_bytes_per_ray(cn, spp_per_launch):
 
 
 KERNEL_NAMES = {0: "k_render_v0", 1: "k_render_v1", 2: "k_render_v2<SCHED=0>", 3: "k_render_v2<NCACHE=1536>",
-                4: "k_wf_init+k_wf_extend+k_wf_shade", 5: "k_render_v2<SCHED=1>"}
+                4: "k_wf_init+k_wf_extend+k_wf_shade", 5: "k_render_v2<SCHED=1>", 6: "k_render_v2<SCHED=2>",
+                7: "k_render_v7", 8: "k_render_v2<SCHED=3>", 10: "k_render_v10"}
 
 
 def main():

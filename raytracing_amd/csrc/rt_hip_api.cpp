@@ -41,7 +41,8 @@ template <typename T> struct DevBuf {
       (void)hipFree(ptr);
     ptr = nullptr;
     count = 0;
-    size_t bytes = (n ? n : 1) * sizeof(T);
+    // + 64: kernels may fetch a whole 64-byte line at the last record (k_render_v2 SCHED 3 reads 64 bytes at a 48-byte triangle)
+    size_t bytes = (n ? n : 1) * sizeof(T) + 64;
     hipError_t e = hipMalloc((void **)&ptr, bytes);
     if (e == hipSuccess)
       count = n ? n : 1;
@@ -798,7 +799,7 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
     ctx->variant_auto = true, ctx->variant = 5, ctx->regen_idle = 0;
     return RT_OK;
   }
-  if (!ctx || (variant & 0xFFu) > 10 || (variant & 0xFFu) == 8 || (variant & 0xFFu) == 9)
+  if (!ctx || (variant & 0xFFu) > 10 || (variant & 0xFFu) == 9)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
   ctx->variant_auto = false;
   // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: per-kernel experiment knobs (rt_kernels.hip)

@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     V2_T(ta0);
     V2_CNT(0, state == ST_SHADE);
     if (state == ST_SHADE) {
+      hit.t = closest; // == the accepted t whenever `any`; keeping it out of the traversal loop saves a register
       const bool scattered = shade(sc, any, hit, rng, p);
       ++depth;
       if (scattered && depth < pc.max_depth) {
@@ -476,7 +477,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
                   if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
                     closest = t;
                     any = true;
-                    hit.t = t;
                     hit.u = u;
                     hit.v = v;
                     hit.tri = __float_as_uint(t0.w);
@@ -609,7 +609,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
                   if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
                     closest = t;
                     any = true;
-                    hit.t = t;
                     hit.u = u;
                     hit.v = v;
                     hit.tri = __float_as_uint(t0.w);
@@ -653,6 +652,149 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         }
         V2_T(tb4);
         V2_ACC(7, tb3, tb4);
+      }
+    } else if (SCHED == 3) {
+      // Variant 8 = the vote scheduling of variant 5 with JOINED pair and leaf steps.  With one-triangle
+      // leaves (the reference's SAH builder makes almost only those) a leaf iteration of variant 5 is one
+      // memory round trip for a dozen lanes.  Here an iteration that the vote gives to the pair lanes also
+      // serves the leaf lanes when at least `join_min` of them wait (and the other way round): the loads of
+      // both kinds are issued together, so the wave pays one round trip, then the triangle section and the
+      // pair section run one after the other.  Per lane the sequence of steps is unchanged.
+      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 2u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 4u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 5u;
+      const uint32_t join_code = (sched_arg >> 12) & 7u;
+      const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
+                              : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
+      const uint64_t tri_delta = (uint64_t)(reinterpret_cast<const char *>(sc.tris) - reinterpret_cast<const char *>(sc.pairs));
+      while (true) {
+        const uint32_t kind =
+            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
+        const unsigned long long k1m = __ballot(kind == 1u), k3m = __ballot(kind == 3u);
+        const uint32_t n1 = (uint32_t)__popcll(k1m);
+        const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
+        const uint32_t n3 = (uint32_t)__popcll(k3m);
+        if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
+          break;
+        const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
+        bool do_pop = false;
+        if ((s1 >= s2 && s1 >= s3) || s3 >= s2) {
+          const bool pair_voted = s1 >= s2 && s1 >= s3;
+          const bool run1 = pair_voted || n1 >= join_min;  // wave-uniform
+          const bool run3 = !pair_voted || n3 >= join_min; // wave-uniform
+          const bool do1 = run1 && kind == 1u, do3 = run3 && kind == 3u;
+          // One address expression and ONE group of loads for both kinds: the leaf lanes fetch their 48-byte
+          // triangle into the registers the pair lanes fetch their record into.  The loads are inline assembly
+          // that narrows EXEC itself, so for the compiler they define the registers for every lane: written as
+          // C++ loads under `if (do1 || do3)`, the lanes that do not fetch merge an undefined value with the
+          // loaded one where the branches join, and the compiler then keeps a second set of 14 registers and
+          // copies it every iteration (measured: -13 %).  The compiler does not count these loads: each
+          // consuming section begins with its own s_waitcnt (loads return in order, so the compiler's counts
+          // for its own loads stay sufficient).
+          f4v qx, qy, qz;
+          f2v qr;
+          {
+            // index * stride + base, stride and base selected per lane (no branches)
+            const uint32_t stride = kind == 3u ? 48u : 64u;
+            const uint64_t base = kind == 3u ? (uint64_t)(uintptr_t)sc.tris : (uint64_t)(uintptr_t)sc.pairs;
+            const char *q = reinterpret_cast<const char *>(sc.pairs) +
+                            ((uint64_t)(ref & 0x7FFFFFFFu) * stride + (base - (uint64_t)(uintptr_t)sc.pairs));
+            const unsigned long long m1 = run1 ? k1m : 0ull, m13 = m1 | (run3 ? k3m : 0ull); // wave-uniform
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[m13]\n\t"
+                         "global_load_dwordx4 %[a], %[q], off\n\t"
+                         "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
+                         "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
+                         "s_mov_b64 exec, %[m1]\n\t"
+                         "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
+                         : [q] "v"(q), [m13] "s"(m13), [m1] "s"(m1)
+                         : "memory");
+          }
+          if (do3) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qx), "+v"(qy), "+v"(qz));
+            if (__float_as_uint(qy.w))
+              do_pop = true; // last triangle of the leaf
+            else
+              ref = ref + 1u;
+            V3 v0 = v3(qx.x, qx.y, qx.z), edge_1 = v3(qy.x, qy.y, qy.z), edge_2 = v3(qz.x, qz.y, qz.z);
+            V3 h = cross(cd, edge_2);
+            float a = dot(edge_1, h);
+            if (!(a > -kEpsilon && a < kEpsilon)) {
+              float f = 1.f / a;
+              V3 s = co - v0;
+              float u = f * dot(s, h);
+              if (!(u < 0 || u > 1)) {
+                V3 qq = cross(s, edge_1);
+                float v = f * dot(cd, qq);
+                if (!(v < 0 || u + v > 1)) {
+                  float t = f * dot(edge_2, qq);
+                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
+                    closest = t;
+                    any = true;
+                    hit.u = u, hit.v = v, hit.tri = __float_as_uint(qx.w), hit.inst = cur_inst;
+                  }
+                }
+              }
+            }
+          }
+          if (do1) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
+            const float4 px = make_float4(qx.x, qx.y, qx.z, qx.w), py = make_float4(qy.x, qy.y, qy.z, qy.w),
+                         pz = make_float4(qz.x, qz.y, qz.z, qz.w), pr = make_float4(qr.x, qr.y, 0.f, 0.f);
+            float dist1, dist2;
+            if (fast) {
+              slab_pair_fast<MODE>(co, cd, cinv, px, py, pz, closest, dist1, dist2);
+            } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
+              float4 lo0, hi0, lo1, hi1;
+              unpack_pair(px, py, pz, pr, lo0, hi0, lo1, hi1);
+              dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+              dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+            }
+            uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
+            if (dist1 > dist2) {
+              float tf = dist1;
+              dist1 = dist2;
+              dist2 = tf;
+              uint32_t tc = c1;
+              c1 = c2;
+              c2 = tc;
+            }
+            if (dist1 == kMiss) {
+              do_pop = true;
+            } else {
+              if (dist2 != kMiss)
+                st.push(c2);
+              ref = c1;
+            }
+          }
+        } else {
+          if (kind == 2u) {
+            cur_inst = ref & 0x3FFFFFFFu;
+            const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+            float4 a = q[0], b = q[1], c = q[2], e = q[3];
+            V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
+               c3 = v3(e.x, e.y, e.z);
+            co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
+            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+            st.push(RT_REF_SENTINEL);
+            ref = __float_as_uint(a.w);
+          }
+        }
+        if (do_pop) {
+          while (true) {
+            if (st.sp == 0) {
+              state = ST_SHADE;
+              break;
+            }
+            ref = st.pop();
+            if (ref != RT_REF_SENTINEL)
+              break;
+            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+          }
+        }
       }
     } else
     do {
@@ -747,7 +889,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             continue;
           closest = t;
           any = true;
-          hit.t = t;
           hit.u = u;
           hit.v = v;
           hit.tri = __float_as_uint(t0.w);
@@ -951,9 +1092,11 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   // experiment knobs: variant 2/3 bits 24..30 = pixel-queue bands (8 = one per XCD; measured slower);
   // variants 5/6 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
   const uint32_t kernel = variant & 0xFFu;
-  const bool vote = kernel == 5 || kernel == 6;
+  const bool vote = kernel == 5 || kernel == 6 || kernel == 8;
   const uint32_t nbands = (!vote && ((variant >> 24) & 0x7Fu)) ? ((variant >> 24) & 0x7Fu) : 1u;
-  const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u);
+  // variant 8 bits 28..30 = join threshold code (k_render_v2, SCHED 3)
+  const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u) |
+                         (kernel == 8 ? ((variant >> 28) & 7u) << 12 : 0u);
   hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
@@ -964,7 +1107,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     // experiment knob (variants 5/6, bits 28..30): run at 1..3 waves/SIMD instead of 4 by padding the
     // workgroup's LDS allocation — measures how much the kernel gains from each extra resident wave
     size_t lds_bytes = RT_LDS_STACK * RT_BLOCK * 4;
-    const uint32_t occ = vote ? (variant >> 28) & 7u : 0u;
+    const uint32_t occ = (kernel == 5 || kernel == 6) ? (variant >> 28) & 7u : 0u;
     if (occ >= 1 && occ <= 3) {
       lds_bytes = (size_t)(160 * 1024 / occ) - 512;
       blocks = blocks_for(occ, RT_BLOCK);
@@ -987,7 +1130,12 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                      reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
                      sched)
     const bool rcp = pc.aabb_mode == RT_AABB_RCP;
-    if (kernel == 6) {
+    if (kernel == 8) {
+      if (rcp)
+        RT_V2S(RT_AABB_RCP, 3);
+      else
+        RT_V2S(RT_AABB_DIV, 3);
+    } else if (kernel == 6) {
       if (rcp)
         RT_V2S(RT_AABB_RCP, 2);
       else

@@ -96,6 +96,8 @@ VARIANTS = [0, 1, 2, 2 | (1 << 8), 2 | (40 << 8), 3, 3 | (8 << 8), 4, 4 | (1 << 
             5 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 6, 6 | (1 << 31), 6 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
             6 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24), 5 | (1 << 31), 2 | (1 << 31),
             7, 7 | (2 << 28), 7 | (1 << 31), 7 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24),
+            8, 8 | (1 << 28), 8 | (7 << 28), 8 | (1 << 31), 8 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24) | (2 << 28),
+            8 | (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24) | (5 << 28),
             10, 10 | (1 << 31), 10 | (4 << 8) | (9 << 16) | (1 << 20) | (1 << 24), 10 | (100 << 8) | (1 << 16) | (15 << 20) | (15 << 24)]
 
 
@@ -127,7 +129,7 @@ def test_image_bit_exact(ctx, name, sqrt_spp, depth, rng, variant):
     _same_image(got, want)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 5, 6, 7, 10])  # the kernels with the fast slab path
+@pytest.mark.parametrize("variant", [2, 3, 5, 6, 7, 8, 10])  # the kernels with the fast slab path
 @pytest.mark.parametrize("mode", [T.AABB_DIV, T.AABB_RCP])
 @pytest.mark.parametrize("kind,cam_pos", [
     ("tiny_vertex", (0, 0.75, 1.5)), ("huge_vertex", (0, 0.75, 1.5)),

@@ -227,7 +227,7 @@ def test_row_interleave_bookkeeping():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 8, 10])
 def test_interleaved_rows_through_renderer_on_one_gpu(variant):
     """Three renderers play three ranks of the interleaved mode: the stitched image is the single-renderer image
     bit for bit, for every kernel family (they share the row mapping of rt_kernels.h)."""
