@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--variant", type=int, default=5)
+    ap.add_argument("--variant", type=int, default=8)
     ap.add_argument("--shard", choices=["frames", "rows", "interleave"], default="frames",
                     help="N>1: progressive frames round-robin + reduce (default), contiguous row bands + all-gather, "
                          "or interleaved 8-row groups + all-gather")

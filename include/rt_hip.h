@@ -93,12 +93,12 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);
 /* Low byte: 0 reference-structured kernel (one lane per pixel, nested loops);
  * 1 persistent waves with path regeneration; 2 resumable per-lane traversal;
- * 3 = 2 with an LDS node cache; 4 wavefront pipeline; 5 vote-scheduled traversal
- * (the default); 6 = 5 with the stack top in a register; 7 = 5 with cold path state in HBM;
- * 8 = 5 with joined pair and leaf steps (one shared fetch per iteration); 10 pooled scheduling
+ * 3 = 2 with an LDS node cache; 4 wavefront pipeline; 5 vote-scheduled traversal;
+ * 6 = 5 with the stack top in a register; 7 = 5 with cold path state in HBM;
+ * 8 = 5 with joined pair and leaf steps (one shared fetch per iteration; the default); 10 pooled scheduling
  * (128 paths per wave, traversal state in LDS; at most 65535 instances).  Higher bits are
  * schedule knobs (rt_kernels.hip).  Every variant gives the same results bit for bit.
- * RT_KERNEL_VARIANT_AUTO (the state of a new context) lets rt_render choose: variant 5, except variant 0 for a
+ * RT_KERNEL_VARIANT_AUTO (the state of a new context) lets rt_render choose: variant 8, except variant 0 for a
  * tiny scene rendered with at most 4 samples and depth 3 per launch (the reference's live configuration). */
 #define RT_KERNEL_VARIANT_AUTO 0xFFFFFFFFu
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);

@@ -100,7 +100,7 @@ struct rt_ctx {
   bool accum_bound = false;
   rt_camera_uniforms camera{};
   bool have_camera = false;
-  uint32_t variant = 5; // persistent, regenerating, vote-scheduled resumable traversal (k_render_v2<.., SCHED=1>)
+  uint32_t variant = 8; // persistent, regenerating, vote-scheduled traversal with joined pair/leaf steps (k_render_v2<.., SCHED=3>)
   bool variant_auto = true; // rt_render chooses between variants 5 and 0 (RT_KERNEL_VARIANT_AUTO)
   uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
   uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
@@ -534,7 +534,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // one-lane-per-pixel kernel is 1.3x faster (0.40 vs 0.53 ms at 1280x720).  All kernels give the same bits.
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
   const uint32_t variant = !ctx->variant_auto ? ctx->variant
-                           : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 5u;
+                           : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
   const uint32_t kind = variant & 0xFFu;
   const bool wavefront = kind == 4 && pc.max_depth > 0 && pc.max_depth <= 255 &&
                          (uint64_t)pc.sqrt_spp * pc.sqrt_spp < (1u << 24);
@@ -796,7 +796,7 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
 
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
   if (ctx && variant == RT_KERNEL_VARIANT_AUTO) {
-    ctx->variant_auto = true, ctx->variant = 5, ctx->regen_idle = 0;
+    ctx->variant_auto = true, ctx->variant = 8, ctx->regen_idle = 0;
     return RT_OK;
   }
   if (!ctx || (variant & 0xFFu) > 10 || (variant & 0xFFu) == 9)

@@ -660,9 +660,11 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       // serves the leaf lanes when at least `join_min` of them wait (and the other way round): the loads of
       // both kinds are issued together, so the wave pays one round trip, then the triangle section and the
       // pair section run one after the other.  Per lane the sequence of steps is unchanged.
-      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 2u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 4u;
-      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 5u;
+      // Default weights pair : leaf : instance = 1 : 2 : 3 and join threshold 8 lanes, measured (tools/sweep_v8.sh,
+      // sweep_v8b.sh, compare_v8.sh): +2 % over variant 5's 2 : 4 : 5 here, where most leaf steps ride along anyway.
+      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
+      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
+      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 3u;
       const uint32_t join_code = (sched_arg >> 12) & 7u;
       const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
                               : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
@@ -670,19 +672,26 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       while (true) {
         const uint32_t kind =
             state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
-        const unsigned long long k1m = __ballot(kind == 1u), k3m = __ballot(kind == 3u);
-        const uint32_t n1 = (uint32_t)__popcll(k1m);
+        const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
         const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
-        const uint32_t n3 = (uint32_t)__popcll(k3m);
+        const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
         if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
           break;
         const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
         bool do_pop = false;
-        if ((s1 >= s2 && s1 >= s3) || s3 >= s2) {
-          const bool pair_voted = s1 >= s2 && s1 >= s3;
-          const bool run1 = pair_voted || n1 >= join_min;  // wave-uniform
-          const bool run3 = !pair_voted || n3 >= join_min; // wave-uniform
-          const bool do1 = run1 && kind == 1u, do3 = run3 && kind == 3u;
+        // which kinds run this iteration, as ONE wave-uniform integer (bit k = kind k); the lanes derive their
+        // own predicate from it with three vector instructions.  (Uniform bools combined with per-lane
+        // conditions become chains of 64-bit scalar mask instructions: about 30 per iteration, measured.)
+        uint32_t sel;
+        if (s1 >= s2 && s1 >= s3)
+          sel = n3 >= join_min ? 10u : 2u;
+        else if (s3 >= s2)
+          sel = n1 >= join_min ? 10u : 8u;
+        else
+          sel = 4u;
+        const uint32_t act = ((sel >> kind) & 1u) ? kind : 0u; // this lane's step in this iteration, 0 = wait
+        if (sel != 4u) {
+          const bool do1 = act == 1u, do3 = act == 3u;
           // One address expression and ONE group of loads for both kinds: the leaf lanes fetch their 48-byte
           // triangle into the registers the pair lanes fetch their record into.  The loads are inline assembly
           // that narrows EXEC itself, so for the compiler they define the registers for every lane: written as
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             const uint64_t base = kind == 3u ? (uint64_t)(uintptr_t)sc.tris : (uint64_t)(uintptr_t)sc.pairs;
             const char *q = reinterpret_cast<const char *>(sc.pairs) +
                             ((uint64_t)(ref & 0x7FFFFFFFu) * stride + (base - (uint64_t)(uintptr_t)sc.pairs));
-            const unsigned long long m1 = run1 ? k1m : 0ull, m13 = m1 | (run3 ? k3m : 0ull); // wave-uniform
+            const unsigned long long m1 = __ballot(do1), m13 = __ballot(act != 0u);
             unsigned long long saved;
             asm volatile("s_mov_b64 %[sv], exec\n\t"
                          "s_mov_b64 exec, %[m13]\n\t"
@@ -719,26 +728,23 @@ __global__ void __launch_bounds__(BLOCK, MINW)
               do_pop = true; // last triangle of the leaf
             else
               ref = ref + 1u;
+            // the test without its early exits (same operations on the accepted path, so the same bits): four
+            // nested branches cost about 20 scalar instructions and make every value they may change a merge
             V3 v0 = v3(qx.x, qx.y, qx.z), edge_1 = v3(qy.x, qy.y, qy.z), edge_2 = v3(qz.x, qz.y, qz.z);
             V3 h = cross(cd, edge_2);
             float a = dot(edge_1, h);
-            if (!(a > -kEpsilon && a < kEpsilon)) {
-              float f = 1.f / a;
-              V3 s = co - v0;
-              float u = f * dot(s, h);
-              if (!(u < 0 || u > 1)) {
-                V3 qq = cross(s, edge_1);
-                float v = f * dot(cd, qq);
-                if (!(v < 0 || u + v > 1)) {
-                  float t = f * dot(edge_2, qq);
-                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
-                    closest = t;
-                    any = true;
-                    hit.u = u, hit.v = v, hit.tri = __float_as_uint(qx.w), hit.inst = cur_inst;
-                  }
-                }
-              }
-            }
+            float f = 1.f / a;
+            V3 s = co - v0;
+            float u = f * dot(s, h);
+            V3 qq = cross(s, edge_1);
+            float v = f * dot(cd, qq);
+            float t = f * dot(edge_2, qq);
+            const bool accept = !(a > -kEpsilon && a < kEpsilon) & !(u < 0 || u > 1) & !(v < 0 || u + v > 1) &
+                                !(t < kEpsilon || !(0.0001f <= t && t <= closest));
+            closest = accept ? t : closest;
+            any = any | accept;
+            hit.u = accept ? u : hit.u, hit.v = accept ? v : hit.v;
+            hit.tri = accept ? __float_as_uint(qx.w) : hit.tri, hit.inst = accept ? cur_inst : hit.inst;
           }
           if (do1) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
@@ -771,7 +777,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             }
           }
         } else {
-          if (kind == 2u) {
+          if (act == 2u) {
             cur_inst = ref & 0x3FFFFFFFu;
             const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
             float4 a = q[0], b = q[1], c = q[2], e = q[3];
