@@ -768,12 +768,18 @@ __global__ void __launch_bounds__(BLOCK, MINW)
               c1 = c2;
               c2 = tc;
             }
-            if (dist1 == kMiss) {
-              do_pop = true;
-            } else {
-              if (dist2 != kMiss)
+            // branch-light form of "miss: pop; else descend into the near child and push the far one": nested
+            // branches cost scalar instructions at every level, and the spill path of the stack is rare enough
+            // for a wave-uniform test
+            const bool hit1 = dist1 != kMiss, hit2 = dist2 != kMiss; // sorted: hit2 implies hit1
+            do_pop = !hit1;
+            ref = hit1 ? c1 : ref;
+            if (__ballot(hit2 && st.sp >= NLDS) != 0ull) {
+              if (hit2)
                 st.push(c2);
-              ref = c1;
+            } else if (hit2) {
+              st.lds[st.sp * BLOCK] = c2;
+              ++st.sp;
             }
           }
         } else {
@@ -789,16 +795,18 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             ref = __float_as_uint(a.w);
           }
         }
-        if (do_pop) {
-          while (true) {
-            if (st.sp == 0) {
-              state = ST_SHADE;
-              break;
-            }
+        if (do_pop) { // at most two pops: the entry under a sentinel is a TLAS reference, never another sentinel
+          if (st.sp == 0) {
+            state = ST_SHADE;
+          } else {
             ref = st.pop();
-            if (ref != RT_REF_SENTINEL)
-              break;
-            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+            if (ref == RT_REF_SENTINEL) { // back to world space
+              co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+              if (st.sp == 0)
+                state = ST_SHADE;
+              else
+                ref = st.pop();
+            }
           }
         }
       }
