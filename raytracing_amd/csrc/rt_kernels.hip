@@ -199,6 +199,9 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 // next pixel from the queue) and resumes — the unfinished lanes simply carry
 // on.  Per pixel the sequence of arithmetic and RNG draws is unchanged.
 // ---------------------------------------------------------------------------
+#ifndef RT_V8_MINW
+#define RT_V8_MINW 4 // resident waves per SIMD the default kernel is built for
+#endif
 #ifdef RT_V2_STATS
 __device__ unsigned long long g_v2_stats[32];
 #define V2_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -669,6 +672,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
                               : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
       const uint64_t tri_delta = (uint64_t)(reinterpret_cast<const char *>(sc.tris) - reinterpret_cast<const char *>(sc.pairs));
+      // `any` and `fast` as per-lane integers inside the step loop: as bools they live in scalar lane masks, and
+      // every conditional update costs three scalar instructions where it merges, plus three per loop iteration
+      uint32_t anyv = any ? 1u : 0u, fastv = fast ? 1u : 0u;
       while (true) {
         const uint32_t kind =
             state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
@@ -742,7 +748,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             const bool accept = !(a > -kEpsilon && a < kEpsilon) & !(u < 0 || u > 1) & !(v < 0 || u + v > 1) &
                                 !(t < kEpsilon || !(0.0001f <= t && t <= closest));
             closest = accept ? t : closest;
-            any = any | accept;
+            anyv = accept ? 1u : anyv;
             hit.u = accept ? u : hit.u, hit.v = accept ? v : hit.v;
             hit.tri = accept ? __float_as_uint(qx.w) : hit.tri, hit.inst = accept ? cur_inst : hit.inst;
           }
@@ -751,7 +757,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             const float4 px = make_float4(qx.x, qx.y, qx.z, qx.w), py = make_float4(qy.x, qy.y, qy.z, qy.w),
                          pz = make_float4(qz.x, qz.y, qz.z, qz.w), pr = make_float4(qr.x, qr.y, 0.f, 0.f);
             float dist1, dist2;
-            if (fast) {
+            if (fastv) {
               slab_pair_fast<MODE>(co, cd, cinv, px, py, pz, closest, dist1, dist2);
             } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
               float4 lo0, hi0, lo1, hi1;
@@ -790,7 +796,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
                c3 = v3(e.x, e.y, e.z);
             co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+            bool f2;
+            prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+            fastv = f2 ? 1u : 0u;
             st.push(RT_REF_SENTINEL);
             ref = __float_as_uint(a.w);
           }
@@ -801,7 +809,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
           } else {
             ref = st.pop();
             if (ref == RT_REF_SENTINEL) { // back to world space
-              co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
+              bool f2;
+              co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+              fastv = f2 ? 1u : 0u;
               if (st.sp == 0)
                 state = ST_SHADE;
               else
@@ -810,6 +820,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
           }
         }
       }
+      any = anyv != 0u, fast = fastv != 0u;
     } else
     do {
       // one step per traversing lane: 1 = interior pair, 2 = TLAS leaf (enter an instance), 3 = BLAS leaf
@@ -1102,7 +1113,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
     uint64_t need = (slots + block - 1) / block;
     return (uint32_t)(need < resident ? need : resident);
   };
-  uint32_t blocks = blocks_for(4, RT_BLOCK);
+  uint32_t blocks = blocks_for((variant & 0xFFu) == 8 ? RT_V8_MINW : 4, RT_BLOCK);
   // experiment knobs: variant 2/3 bits 24..30 = pixel-queue bands (8 = one per XCD; measured slower);
   // variants 5/6 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
   const uint32_t kernel = variant & 0xFFu;
@@ -1139,7 +1150,7 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
       }
     }
 #define RT_V2S(MODE, S)                                                                            \
-  hipLaunchKernelGGL((k_render_v2<MODE, 4, RT_BLOCK, RT_LDS_STACK, 0, S>), dim3(blocks),           \
+  hipLaunchKernelGGL((k_render_v2<MODE, (S == 3 ? RT_V8_MINW : 4), RT_BLOCK, RT_LDS_STACK, 0, S>), dim3(blocks),           \
                      dim3(RT_BLOCK), lds_bytes, stream, sc, cam, pc,                               \
                      reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
                      sched)
