@@ -354,3 +354,52 @@ def test_full_size_c3_properties():
     rows = sharding.interleaved_rows(0, 33, h)
     assert len(rows) == 40 and np.array_equal(a[rows].view(np.uint32), want[rows].view(np.uint32))
     r.shutdown()
+
+
+def _chain_scene(n=38, e0=-28):
+    """n cubes at x = 2^(i + e0), each stretched to an eighth of its distance from the origin: the reference's
+    agglomerative TLAS builder (TLAS.cpp:38-58) chains them — ((((0 1) 2) 3) ...) — so a ray along +x pushes one far
+    instance per TLAS level before it enters its first BLAS: 37 stack entries, beyond the 24 the kernels keep in LDS."""
+    r = O.OracleRenderer()
+    cube = r.add_blas(*S.cube_mesh())
+    mats = [r.add_lambert_material((0.6, 0.5, 0.4)), r.add_metal_material((0.8, 0.8, 0.9), 0.05)]
+    for i in range(n):
+        x = float(2.0 ** (i + e0))
+        r.add_blas_instance(cube, O.trs((x, 0, 0), (1, 0, 0, 0), (x / 8, 1, 1)), mats[i & 1])
+    return r
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 8 | (1 << 28), 8 | (7 << 28), 10])
+def test_stack_deeper_than_the_lds_part(ctx, variant):
+    """Traversal stacks that reach into the per-lane spill arrays (more than RT_LDS_STACK = 24 entries): hits and a
+    rendered image stay bit-exact for every kernel, the wave-uniform spill tests of the default kernel included."""
+    sc = _chain_scene().build()
+    rng = np.random.default_rng(7)
+    n = 4096
+    rays = np.zeros(n, T.ray_dtype)
+    rays["origin"] = np.stack([np.full(n, -1.0), rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n)], -1).astype(np.float32)
+    rays["direction"] = np.stack([np.ones(n), rng.normal(scale=2e-4, size=n), rng.normal(scale=2e-4, size=n)], -1).astype(np.float32)
+    rays["origin"][::7] = (600.0, 0.1, -0.2)
+    rays["direction"][::7, 0] = -1.0
+    rays["t_min"], rays["t_max"] = np.float32(1e-4), np.float32(1000.0)
+    cn = O.Counters()
+    want = O.trace_closest(sc, rays, counters=cn)
+    assert cn.max_stack > 30  # the premise of this test
+    ctx.upload_scene(sc)
+    ctx.set_kernel_variant(variant)
+    got = ctx.trace_closest(rays)
+    for k in ("t", "tri_id", "inst_id"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    w, h = 96, 40
+    cam = O.camera_uniforms((-1.0, 0.2, 0.1), (600.0, 0.0, 0.0), (0, 1, 0), 30.0, w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    img = np.zeros((h, w, 4), np.float32)
+    cn2 = O.Counters()
+    p = O.render_params(w, h, 0, 2, 6)
+    ctx.render(p)
+    O.render(sc, cam, p, img, counters=cn2, nthreads=8)
+    assert cn2.max_stack > 30
+    got_img = ctx.read_accum(w, h)
+    ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
+    _same_image(got_img, img)
