@@ -704,8 +704,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
           // C++ loads under `if (do1 || do3)`, the lanes that do not fetch merge an undefined value with the
           // loaded one where the branches join, and the compiler then keeps a second set of 14 registers and
           // copies it every iteration (measured: -13 %).  The compiler does not count these loads: each
-          // consuming section begins with its own s_waitcnt (loads return in order, so the compiler's counts
-          // for its own loads stay sufficient).
+          // consuming section begins with its own s_waitcnt vmcnt(0) (loads return in order, so the compiler's
+          // counts for its own loads stay sufficient), and whenever a load was issued for a lane that lane enters
+          // one of the two sections below in this same iteration, so nothing is left in flight at the loop's end.
+          // Lanes outside m13 keep stale register contents, which no section reads for them.
           f4v qx, qy, qz;
           f2v qr;
           {
