@@ -676,8 +676,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       // every conditional update costs three scalar instructions where it merges, plus three per loop iteration
       uint32_t anyv = any ? 1u : 0u, fastv = fast ? 1u : 0u;
       while (true) {
-        const uint32_t kind =
-            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
+        // 1 pair, 2 instance, 3 leaf from the two top bits of the reference (00 -> 1, 10 -> 3, 11 -> 2) by a packed
+        // table, 0 when not traversing: no branch
+        const uint32_t top2 = ref >> 30;
+        const uint32_t kind = (state == ST_TRAVERSE ? 3u : 0u) & (0xB5u >> (top2 * 2u)); // table 01 -> 1 as well
         const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
         const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
         const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
