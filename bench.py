@@ -5,25 +5,29 @@ Workload (N=1): dragon-class mesh (procedural stand-in, 870,400 triangles, seed
 1234 — the reference's dragon.obj is missing from its snapshot) on a ground
 plane under the sky gradient, 1920x1080, 256 spp per step (one launch of the
 path-tracing megakernel with a 16x16 stratified grid), max_depth 8, reference
-RNG (Wang) and reference slab arithmetic (division).  A step is one full frame;
-successive steps are successive progressive frames (RayTracing.slang:176-179).
+slab arithmetic (division); `--rng wang` (default) is the reference's sequential
+Wang hash, `--rng pcg` the keyed PCG that north_star names.  A step is one full
+frame; successive steps are successive progressive frames (RayTracing.slang:176-179).
 
-N>1 (one process per GPU, RCCL): the scene is replicated, rank r renders the
-progressive frames r, r+N, ... (the reference reseeds per frame_index, so frames
-are independent sample sets); after every step the per-GPU running means are
-summed onto rank 0 with one RCCL reduce inside the timed region.  Per-GPU work
-is fixed => "scaling": "weak".
+N>1 (one process per GPU, RCCL): the scene is replicated and every frame is cut
+into groups of 8 rows dealt round-robin to the ranks (`--shard interleave`, the
+default: SURVEY.md §8(e)); after every step the groups are all-gathered, so every
+rank holds the complete image, bit-identical to the one-GPU image.  The exchange
+of step k runs on its own stream while step k+1 renders.  Total work is fixed =>
+"scaling": "strong".  `--shard frames` (rank r renders frames r, r+N, ...; one
+RCCL sum-reduce per step; weak scaling) and `--shard rows` (contiguous bands) remain.
 
 The CPU baseline is the oracle (oracle/liboracle.so, kind "port": the
 reference's own CPU path does not exist) timed on rank 0 on a
 bounded sample of the same workload; the same oracle run supplies the
 algorithmic bytes per ray of the roofline and a bit-exact
-parity check of a band of the GPU image.
+parity check of the GPU image.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,33 +39,68 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_dragon_scene(R, renderer):
-    """C3: dragon stand-in + ground plane, lambert, sky lit."""
+def build_dragon_scene(R, renderer, defocus=False):
+    """C3: dragon stand-in + ground plane, lambert, sky lit.  defocus=True: the C5 camera (thin lens focused on
+    the dragon, Random.slang:57-70 semantics)."""
     mesh = R.Mesh.dragon(1700, 256, 1234)
     dragon = renderer.add_blas(mesh)
     body = renderer.add_lambert_material((0.55, 0.62, 0.35))
     ground = renderer.add_lambert_material((0.6, 0.6, 0.6))
     renderer.add_blas_instance(dragon, R.trs(), body)
     renderer.add_blas_instance(renderer.plane_blas_index, R.trs((0, -0.28, 0), 0.0, (0, 1, 0), (14, 1, 14)), ground)
-    cam = R.Camera((0.6, 1.7, 3.9), (0.15, 0.5, 0.0), (0, 1, 0), 40.0)
+    if defocus:
+        cam = R.Camera((0.6, 1.7, 3.9), (0.15, 0.5, 0.0), (0, 1, 0), 40.0, defocus_angle=0.8, focus_dist=4.1)
+    else:
+        cam = R.Camera((0.6, 1.7, 3.9), (0.15, 0.5, 0.0), (0, 1, 0), 40.0)
     return cam, mesh.triangle_count + 2
 
 
-def algorithmic_bytes_per_ray(cn, spp_per_launch):
-    """SURVEY.md §8(d), reference layouts: per interior visit two 32-B child
-    nodes; per TLAS leaf a 144-B instance + 16-B BLAS record; per triangle test
-    4-B tri id + 48-B TriangleGeom; per shaded hit 80-B TriangleShading + 144-B
-    instance + 8-B material (lambert index + 1x1 texel); per pixel-sample the
-    rgba32f read-modify-write amortised over the launch's samples."""
+def reference_layout_bytes_per_ray(cn, spp_per_launch):
+    """SURVEY.md §8(d), the figure `roofline.achieved` is defined on — REFERENCE layouts: per interior visit two
+    32-B child nodes; per TLAS leaf a 144-B instance + 16-B BLAS record; per triangle test 4-B tri id + 48-B
+    TriangleGeom; per shaded hit 80-B TriangleShading + 144-B instance + 8-B material (lambert index + 1x1 texel);
+    per pixel-sample the rgba32f read-modify-write amortised over the launch's samples."""
     rays = max(cn["rays"], 1)
     trav = 64 * cn["tlas_interior"] + 160 * cn["tlas_leaf"] + 64 * cn["blas_interior"] + 52 * cn["tris_tested"]
     shade = (80 + 144 + 8) * cn["shaded_hits"]
     return (trav + shade) / rays, 32.0 / spp_per_launch
 
 
-KERNEL_NAMES = {0: "k_render_v0", 1: "k_render_v1", 2: "k_render_v2<SCHED=0>", 3: "k_render_v2<NCACHE=1536>",
-                4: "k_wf_init+k_wf_extend+k_wf_shade", 5: "k_render_v2<SCHED=1>", 6: "k_render_v2<SCHED=2>",
-                7: "k_render_v7", 8: "k_render_v2<SCHED=3>", 10: "k_render_v10"}
+def product_layout_bytes_per_ray(cn, spp_per_launch):
+    """The bytes THIS library's kernels request for the same visits (rt_device_layout.h): 56 of a 64-B pair record
+    per interior visit, a 64-B rt_dev_inst per TLAS leaf, a 48-B rt_dev_tri per triangle test, per shaded hit the
+    176-B rt_dev_inst_shade + 80-B TriangleShading."""
+    rays = max(cn["rays"], 1)
+    trav = 56 * (cn["tlas_interior"] + cn["blas_interior"]) + 64 * cn["tlas_leaf"] + 48 * cn["tris_tested"]
+    shade = (176 + 80) * cn["shaded_hits"]
+    return (trav + shade) / rays, 32.0 / spp_per_launch
+
+
+KERNEL_NAMES = {0: "k_render_v0", 8: "k_render_v8", 9: "k_wf_*"}
+
+
+def host_threads(requested):
+    """Threads for the CPU baseline: every CPU this process may use.  On the GPU box os.cpu_count() shows the whole
+    machine while the job owns a share of it (OMP_NUM_THREADS is set to that share), so the smaller wins."""
+    if requested > 0:
+        return requested
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    if omp.isdigit() and int(omp) > 0:
+        n = min(n, int(omp))
+    return max(n, 1)
+
+
+def git_commit():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
+                                       text=True).strip()
+    except Exception:
+        return None
 
 
 def main():
@@ -74,16 +113,20 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--variant", type=int, default=8)
-    ap.add_argument("--shard", choices=["frames", "rows", "interleave"], default="frames",
-                    help="N>1: progressive frames round-robin + reduce (default), contiguous row bands + all-gather, "
-                         "or interleaved 8-row groups + all-gather")
+    ap.add_argument("--rng", choices=["wang", "pcg"], default="wang")
+    ap.add_argument("--defocus", action="store_true", help="the C5 camera: thin lens instead of the pinhole")
+    ap.add_argument("--variant", type=lambda s: int(s, 0), default=0xFFFFFFFF,
+                    help="kernel variant (default: RT_KERNEL_VARIANT_AUTO, the library's choice)")
+    ap.add_argument("--shard", choices=["interleave", "frames", "rows"], default="interleave",
+                    help="N>1: interleaved 8-row groups + overlapped all-gather (default, bit-identical to one GPU), "
+                         "progressive frames round-robin + reduce, or contiguous row bands + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the gather-ceiling probe (rt_debug_probe_walk)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 on a box with fewer GPUs than ranks: ranks share the GPUs (local_rank %% device_count) and "
                          "talk over gloo instead of RCCL.  Exercises the multi-rank code path; its numbers mean nothing.")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may use")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,24 +158,29 @@ def main():
     W, H = args.width, args.height
     sqrt_spp = int(round(args.spp ** 0.5))
     assert sqrt_spp * sqrt_spp == args.spp, "--spp must be a perfect square (Renderer.cpp:625)"
+    rng_mode = T.RNG_PCG if args.rng == "pcg" else T.RNG_WANG
+    aabb_mode = T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV
 
     t_setup = time.time()
     r = R.Renderer(W, H, device=local_rank)
-    cam, n_tris = build_dragon_scene(R, r)
+    cam, n_tris = build_dragon_scene(R, r, defocus=args.defocus)
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
     r.set_option(R.OPT_MAX_DEPTH, args.depth)
-    r.set_option(R.OPT_AABB_MODE, T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV)
+    r.set_option(R.OPT_AABB_MODE, aabb_mode)
+    r.set_option(R.OPT_RNG_MODE, rng_mode)
     bands, interleave = None, None
-    if args.shard == "rows" and world > 1:  # every rank renders its row band of every frame
+    mode = "none" if world == 1 else args.shard
+    if mode == "rows":  # every rank renders its row band of every frame
         bands = [sharding.row_shard(k, world, H) for k in range(world)]
         r.set_option(R.OPT_ROW_BEGIN, bands[rank][0])
         r.set_option(R.OPT_ROW_END, bands[rank][1])
-    elif args.shard == "interleave" and world > 1:  # every rank renders row groups rank, rank+N, ... of every frame
+    elif mode == "interleave":  # every rank renders row groups rank, rank+N, ... of every frame
         interleave = sharding.row_interleave(rank, world, H)
+        assert interleave is not None, "more ranks than 8-row groups"
         r.set_option(R.OPT_ROW_BEGIN, interleave["row_begin"])
         r.set_option(R.OPT_ROW_END, interleave["row_end"])
         r.set_option(R.OPT_ROW_GROUP_STRIDE, interleave["row_group_stride"])
-    else:
+    elif mode == "frames":
         shard = sharding.frame_shard(rank, world)
         r.set_option(R.OPT_FRAME_STRIDE, shard["frame_stride"])
         r.set_option(R.OPT_FRAME_OFFSET, shard["frame_offset"])
@@ -143,20 +191,36 @@ def main():
     # the accumulation image lives in a torch tensor so RCCL can read it
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(accum.data_ptr()), W, H))
-    reduced = torch.empty_like(accum) if world > 1 else None
+    reduced = torch.empty_like(accum) if mode in ("frames",) else None
+    s_render = s_comm = gather = None
+    if mode == "interleave":
+        # launches go on a torch stream of ours, so the exchange can be ordered behind them with stream events
+        s_render, s_comm = torch.cuda.Stream(), torch.cuda.Stream()
+        _ffi._check(L.rt_set_stream(ctx, C.c_void_p(s_render.cuda_stream)))
+        gather = sharding.InterleavedGather(H, W, device="cuda")
+        comm_done = [None, None]
     setup_s = time.time() - t_setup
 
     def step():
-        r.render(cam)          # one launch: args.spp samples for every pixel
-        if world > 1:
-            r.wait()           # kernel runs on the library's stream
-            if interleave is not None:
-                sharding.gather_interleaved(accum)       # every rank: the complete image, bit-exact
-            elif bands is not None:
-                sharding.gather_rows(accum, bands)       # every rank: the complete image, bit-exact
-            else:
-                sharding.combine(accum, out=reduced, dst=0)  # rank 0: (1/N) * sum of the N running means
-            # the collective reads `accum` on torch's stream; the next launch writes it on the library's
+        r.render(cam)          # one launch: args.spp samples for every pixel of this rank's rows
+        if mode == "interleave":
+            with torch.cuda.stream(s_render):
+                k = gather.step & 1
+                if comm_done[k] is not None:
+                    s_render.wait_event(comm_done[k])   # the packed buffer of two steps ago has been sent
+                slot = gather.pack(accum)               # behind the launch, on its stream
+                packed = s_render.record_event()
+            with torch.cuda.stream(s_comm):
+                s_comm.wait_event(packed)
+                gather.exchange(slot)                   # every rank: the complete image, bit-exact; the next
+                comm_done[slot] = s_comm.record_event()  # step's launch does not wait for this
+        elif mode == "rows":
+            r.wait()
+            sharding.gather_rows(accum, bands)          # every rank: the complete image, bit-exact
+            torch.cuda.current_stream().synchronize()
+        elif mode == "frames":
+            r.wait()
+            sharding.combine(accum, out=reduced, dst=0)  # rank 0: (1/N) * sum of the N running means
             torch.cuda.current_stream().synchronize()
 
     def fence():
@@ -181,40 +245,74 @@ def main():
     rays_local = float(st.rays_traced)
     vals = torch.tensor([elapsed, rays_local, st.total_kernel_ms], dtype=torch.float64,
                         device="cpu" if args.rehearse else "cuda")
+    per_rank_kernel_ms = [st.total_kernel_ms / max(st.launches, 1)]
     if world > 1:
         tmax = vals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = vals.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed_max, rays_total = float(tmax[0]), float(tsum[1])
+        allv = [torch.zeros_like(vals) for _ in range(world)]
+        dist.all_gather(allv, vals)
+        per_rank_kernel_ms = [float(v[2]) / max(st.launches, 1) for v in allv]
     else:
         elapsed_max, rays_total = elapsed, rays_local
 
+    # N>1 parity: rank 0 re-renders, on its own, a sample of row groups that OTHER ranks rendered, over all
+    # warmup + timed frames, and compares them with the gathered image bit for bit
+    parity = None
+    frames_done = args.warmup + args.steps
+    if mode == "interleave" and rank == 0 and frames_done > 0:
+        groups = (H + 7) // 8
+        sample = [g for g in range(groups) if g % world != 0]
+        sample = sample[:: max(1, len(sample) // 5)][:5]
+        chk = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(chk.data_ptr()), W, H))
+        camu = r.camera_uniforms(cam)
+        _ffi._check(L.rt_set_camera(ctx, C.byref(camu)))
+        for f in range(frames_done):
+            for g in sample:
+                p = T.RenderParams()
+                p.image_width, p.image_height, p.frame_index, p.accum_count = W, H, f, f
+                p.sqrt_spp, p.max_depth, p.rng_mode, p.aabb_mode = sqrt_spp, args.depth, rng_mode, aabb_mode
+                p.row_begin, p.row_end = g * 8, min(g * 8 + 8, H)
+                _ffi._check(L.rt_render(ctx, C.byref(p)))
+        r.wait()
+        torch.cuda.synchronize()
+        rows = [y for g in sample for y in range(g * 8, min(g * 8 + 8, H))]
+        a = gather.full[rows].cpu().numpy().view(np.uint32)
+        b = chk[rows].cpu().numpy().view(np.uint32)
+        parity = {"pixels": len(rows) * W, "differing": int((a != b).any(-1).sum()), "frames": frames_done,
+                  "bar": "gathered N-rank image == rank 0's own render of row groups other ranks rendered, bit-exact"}
+        _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(accum.data_ptr()), W, H))
+
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     kernel_ms = st.total_kernel_ms / max(st.launches, 1)
     rays_per_launch = rays_local / max(st.launches, 1)
     value = rays_total / elapsed_max / 1e6
+    kernel_id = st.last_kernel  # read before the parity launches: what the timed launches ran
 
-    cpu_baseline, roofline, parity = None, None, None
-    bytes_per_ray = None
+    cpu_baseline, roofline = None, None
+    bytes_per_ray = product_bytes = None
+    cnd = None
     if not args.no_cpu_baseline:
         # rank 0 only.  N = 1: the timed CPU baseline; N > 1: one oracle frame, untimed, for the algorithmic byte
         # counters the roofline needs (cpu_baseline stays null there, as the contract asks)
         from tests import _oracle as O
         sa = r.scene_arrays()                 # the product-built arrays, handed to the checker
         camu = r.camera_uniforms(cam)
-        nthreads = args.cpu_threads
+        nthreads = host_threads(args.cpu_threads)
         cn = O.Counters()
         img = np.zeros((H, W, 4), np.float32)
         cpu_sqrt = 2
         frames, t_cpu = 0, 0.0
         while (t_cpu < args.cpu_seconds and frames < 64) if world == 1 else frames < 1:
-            p = O.render_params(W, H, frames, cpu_sqrt, args.depth,
-                                aabb_mode=T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV)
+            p = O.render_params(W, H, frames, cpu_sqrt, args.depth, rng_mode=rng_mode, aabb_mode=aabb_mode)
             t1 = time.perf_counter()
             O.render(sa, camu, p, img, counters=cn, nthreads=nthreads)
             t_cpu += time.perf_counter() - t1
@@ -222,18 +320,21 @@ def main():
         cnd = cn.as_dict()
         if world == 1:
             cpu_baseline = {"value": cnd["rays"] / t_cpu / 1e6, "unit": "Mrays/s", "cores": nthreads, "kind": "port",
+                            "host_cpus": os.cpu_count(),
                             "sample": f"{frames} progressive frame(s) of {cpu_sqrt * cpu_sqrt} spp, full {W}x{H}, "
                                       f"depth {args.depth}, {cnd['rays']} rays in {t_cpu:.2f} s (oracle/liboracle.so, "
-                                      f"{nthreads} threads)"}
-        trav_b, accum_b = algorithmic_bytes_per_ray(cnd, args.spp)
+                                      f"{nthreads} threads = the CPUs this job may use; the machine shows "
+                                      f"{os.cpu_count()})"}
         rays_per_sample = cnd["rays"] / (frames * cpu_sqrt * cpu_sqrt * W * H)
+        trav_b, accum_b = reference_layout_bytes_per_ray(cnd, args.spp)
         bytes_per_ray = trav_b + accum_b / rays_per_sample
+        trav_p, accum_p = product_layout_bytes_per_ray(cnd, args.spp)
+        product_bytes = trav_p + accum_p / rays_per_sample
     if not args.no_cpu_baseline and world == 1:
         # parity spot check: the first oracle frame vs the same launch on the GPU
-        nthreads = args.cpu_threads
         chk = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(chk.data_ptr()), W, H))
-        p0 = O.render_params(W, H, 0, cpu_sqrt, args.depth, aabb_mode=T.AABB_RCP if args.aabb == "rcp" else T.AABB_DIV)
+        p0 = O.render_params(W, H, 0, cpu_sqrt, args.depth, rng_mode=rng_mode, aabb_mode=aabb_mode)
         _ffi._check(L.rt_set_camera(ctx, C.byref(camu)))
         _ffi._check(L.rt_render(ctx, C.byref(p0)))
         r.wait()
@@ -244,36 +345,68 @@ def main():
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(accum.data_ptr()), W, H))
     if bytes_per_ray is not None:
         achieved = bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        # the PMC passes were taken on the default workload; other shapes report no traffic figure
-        if os.path.exists(tpath) and (W, H, args.spp, args.depth, args.aabb) == (1920, 1080, 256, 8, "div"):
+        # the PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh) taken on the default workload; the figure
+        # is read from their committed summary, not measured in this process: other shapes report none
+        if world == 1 and os.path.exists(tpath) and \
+                (W, H, args.spp, args.depth, args.aabb, args.rng, args.defocus) == (1920, 1080, 256, 8, "div", "wang", False):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tdoc = json.load(open(tpath))
+                traffic = tdoc.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  f"tools/profile_pmc.sh, kernel {tdoc.get('kernel')}, taken at commit "
+                                  f"{tdoc.get('commit', 'unrecorded')}; not measured in this run)")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                    "kernel": KERNEL_NAMES.get(args.variant & 0xFF, "?"), "kernel_ms": kernel_ms,
-                    "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch}
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": KERNEL_NAMES.get(kernel_id, "?"), "kernel_ms": kernel_ms,
+                    "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+                    "definition": "SURVEY.md 8(d): bytes counted with the REFERENCE's record sizes for the visits the "
+                                  "oracle counts; most of them are cache hits here (scene resident in the 256 MB "
+                                  "Infinity Cache), so this is not achieved HBM bandwidth — see requested_* and "
+                                  "gather_ceiling for the roofs that bind",
+                    "requested_bytes_per_ray": product_bytes,
+                    "requested_GBps": product_bytes * rays_per_launch / (kernel_ms * 1e-3) / 1e9,
+                    "traffic_frac_of_peak": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None}
+        if not args.no_probe and world == 1 and cnd is not None:
+            # the roof that binds: dependent divergent 64-B record gathers through L1/L2, measured here
+            # by walking the same node records with no arithmetic at the kernel's occupancy (4 waves per SIMD)
+            best = 0.0
+            for _ in range(3):
+                ms, steps = C.c_double(), C.c_uint64()
+                _ffi._check(L.rt_debug_probe_walk(ctx, 256 * 4, 2000, 4, C.byref(ms), C.byref(steps)))
+                best = max(best, steps.value / (ms.value * 1e-3))
+            visits_per_ray = (cnd["tlas_interior"] + cnd["blas_interior"] + cnd["tlas_leaf"] + cnd["tris_tested"]) / max(cnd["rays"], 1)
+            kernel_rate = visits_per_ray * rays_per_launch / (kernel_ms * 1e-3)
+            roofline["gather_ceiling"] = {"visits_per_s": best, "kernel_visits_per_s": kernel_rate,
+                                          "frac": kernel_rate / best, "record_visits_per_ray": visits_per_ray,
+                                          "how": "rt_debug_probe_walk: 1024 blocks x 256 lanes, 2000 dependent 64-B "
+                                                 "record gathers per lane over this scene's node records, best of 3"}
 
+    sharding_txt = {"none": "none", "interleave": "interleaved 8-row groups per rank, RCCL all-gather per step overlapped "
+                    "with the next launch", "rows": "row bands per rank, RCCL all-gather per step",
+                    "frames": "progressive frames round-robin over ranks, RCCL reduce per step"}[mode]
+    strong = mode in ("interleave", "rows")
     out = {
         "metric": "Mrays/s (incl. bounces) dragon scene", "value": value, "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if (bands is not None or interleave is not None) else "weak",
+        "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL: shared GPU, gloo)",
-        "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)", "triangles": n_tris,
-                   "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
-                   "rng": "wang", "aabb": args.aabb, "kernel_variant": args.variant,
-                   "sharding": ("none" if world == 1 else "interleaved 8-row groups per rank, RCCL all-gather per step"
-                                if interleave is not None else "row bands per rank, RCCL all-gather per step" if bands is not None
-                                else "progressive frames round-robin over ranks, RCCL reduce per step")},
-        "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * (1 if (bands is not None or interleave is not None) else world))),
+        "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)" + (", C5 thin-lens camera" if args.defocus else ""),
+                   "triangles": n_tris, "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
+                   "rng": args.rng, "aabb": args.aabb, "kernel": KERNEL_NAMES.get(kernel_id, "?"), "sharding": sharding_txt},
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "kernel_ms_per_launch_by_rank": per_rank_kernel_ms,
+        "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * (1 if strong or world == 1 else world))),
         "rays_per_step": rays_total / args.steps, "kernel_ms_per_launch": kernel_ms,
         "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity,
+        "commit": git_commit(),
     }
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -41,7 +41,7 @@ typedef struct rt_stats {
   double total_kernel_ms; /* sum over launches since rt_reset_stats */
   uint64_t launches;
   uint32_t stack_depth_needed; /* TLAS depth + 1 + deepest BLAS of the scene */
-  uint32_t reserved;
+  uint32_t last_kernel; /* kernel the most recent rt_render launched (0 or 8; what RT_KERNEL_VARIANT_AUTO resolved to) */
   uint64_t device_bytes; /* scene bytes resident in HBM */
 } rt_stats;
 
@@ -59,6 +59,13 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *scene);
 int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances,
                         uint32_t instance_count, const rt_tlas_node *tlas_nodes,
                         uint32_t tlas_node_count);
+
+/* replaces `device->get_current_cmd_buffer()`, src/Renderer.cpp:563: the reference records its dispatch into the
+ * caller's per-frame command buffer; here the caller may hand over the HIP stream (a hipStream_t, e.g. a torch
+ * stream's handle) that every later launch, clear and copy of this context is queued on, so that its own work —
+ * a collective that reads the image — can be ordered against the render with stream events instead of host waits.
+ * NULL reverts to the context's own stream.  Waits for the work already queued on the old stream. */
+int rt_set_stream(rt_ctx *ctx, void *hip_stream);
 
 /* replaces the uniform-buffer memcpy, src/Renderer.cpp:532-561 */
 int rt_set_camera(rt_ctx *ctx, const rt_camera_uniforms *camera);
@@ -91,15 +98,13 @@ int rt_accum_device_ptr(rt_ctx *ctx, void **out_device_ptr);
 int rt_sync(rt_ctx *ctx);
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);
-/* Low byte: 0 reference-structured kernel (one lane per pixel, nested loops);
- * 1 persistent waves with path regeneration; 2 resumable per-lane traversal;
- * 3 = 2 with an LDS node cache; 4 wavefront pipeline; 5 vote-scheduled traversal;
- * 6 = 5 with the stack top in a register; 7 = 5 with cold path state in HBM;
- * 8 = 5 with joined pair and leaf steps (one shared fetch per iteration; the default); 10 pooled scheduling
- * (128 paths per wave, traversal state in LDS; at most 65535 instances).  Higher bits are
- * schedule knobs (rt_kernels.hip).  Every variant gives the same results bit for bit.
- * RT_KERNEL_VARIANT_AUTO (the state of a new context) lets rt_render choose: variant 8, except variant 0 for a
- * tiny scene rendered with at most 4 samples and depth 3 per launch (the reference's live configuration). */
+/* Low byte: 0 = reference-structured kernel (one lane per pixel, nested sample / bounce / traversal loops);
+ * 8 = persistent wave64s with path regeneration, a resumable per-lane traversal, vote scheduling and joined
+ * pair / leaf steps (the default).  Higher bits are schedule knobs of kernel 8 (rt_kernels.hip, rt_launch_render).
+ * Both give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new context) lets rt_render
+ * choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and depth 3 per launch (the
+ * reference's live configuration).  rt_stats.last_kernel reports the choice.  The kernels that round 1 measured
+ * and dropped (numbers 1-7, 10) are in experiments/r01_variants/, outside the library. */
 #define RT_KERNEL_VARIANT_AUTO 0xFFFFFFFFu
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
     "rt_last_error_string",
     "rt_device_count",
 ]
@@ -31,7 +31,7 @@ KERNEL_VARIANT_AUTO = 0xFFFFFFFF  # RT_KERNEL_VARIANT_AUTO: rt_render chooses (a
 class Stats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("last_kernel_ms", C.c_double),
                 ("total_kernel_ms", C.c_double), ("launches", C.c_uint64),
-                ("stack_depth_needed", C.c_uint32), ("reserved", C.c_uint32),
+                ("stack_depth_needed", C.c_uint32), ("last_kernel", C.c_uint32),
                 ("device_bytes", C.c_uint64)]
 
 
@@ -79,6 +79,7 @@ def lib():
     L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rt_reset_stats.argtypes = [vp]
     L.rt_set_kernel_variant.argtypes = [vp, u32]
+    L.rt_set_stream.argtypes = [vp, vp]
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -189,6 +190,10 @@ class HipContext:
 
     def reset_stats(self):
         _check(lib().rt_reset_stats(self._h))
+
+    def set_stream(self, hip_stream):
+        """hip_stream: a hipStream_t as an integer (torch.cuda.Stream().cuda_stream), or None for the context's own."""
+        _check(lib().rt_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))

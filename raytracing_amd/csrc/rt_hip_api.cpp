@@ -12,7 +12,6 @@
 #include "../../include/rt_hip.h"
 #include "rt_flatten.h"
 #include "rt_kernels.h"
-#include "rt_wavefront.h"
 
 namespace {
 
@@ -64,7 +63,8 @@ struct EventPair {
 
 struct rt_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // the stream every launch and copy is queued on
+  hipStream_t own_stream = nullptr; // created by rt_create; `stream` unless the caller set one (rt_set_stream)
   // scene in HBM
   DevBuf<rt_dev_pair> pairs;
   DevBuf<rt_dev_tri> tris;
@@ -74,12 +74,7 @@ struct rt_ctx {
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
-  DevBuf<uint8_t> cold;   // per-lane path state of k_render_v7 (variant 7), allocated on first use
-  DevBuf<uint8_t> cold10; // per-slot path state + stack spill of k_render_v10 (variant 10), allocated on first use
   uint32_t cus = 0;       // compute units of the device
-  DevBuf<uint8_t> wf_mem; // path state of the wavefront pipeline (variant 4)
-  uint32_t wf_w = 0, wf_h = 0;
-  uint32_t wf_pair_min = 40, wf_refill_min = 16, wf_occ = 4;
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -100,9 +95,10 @@ struct rt_ctx {
   bool accum_bound = false;
   rt_camera_uniforms camera{};
   bool have_camera = false;
-  uint32_t variant = 8; // persistent, regenerating, vote-scheduled traversal with joined pair/leaf steps (k_render_v2<.., SCHED=3>)
-  bool variant_auto = true; // rt_render chooses between variants 5 and 0 (RT_KERNEL_VARIANT_AUTO)
+  uint32_t variant = 8; // persistent, regenerating, vote-scheduled traversal with joined pair/leaf steps (k_render_v8)
+  bool variant_auto = true; // rt_render chooses between variants 8 and 0 (RT_KERNEL_VARIANT_AUTO)
   uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
+  uint32_t last_kernel = 0; // kernel of the most recent rt_render
   uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
   // timing
   std::vector<EventPair> pending, free_events;
@@ -180,8 +176,9 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
     root += base;
   // Renumber so that the top of the scene comes first: breadth-first from the
   // TLAS root, through instance leaves into each BLAS once, for the first
-  // RT_CACHE_PAIRS records (the LDS-resident set of k_render_v2<.., NCACHE>);
-  // the rest keep their depth-first order behind them.
+  // RT_CACHE_PAIRS records (every ray walks through them: one dense 96-KiB region
+  // instead of records scattered over the arrays of several BLASes); the rest keep
+  // their depth-first order behind them.
   std::vector<rt_dev_inst> insts(f.insts);
   uint32_t cached = 0;
   {
@@ -247,11 +244,18 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
           moderate = false;
       }
   }
+  // an error return below must not leave copies from these (or the caller's) host arrays queued
+  auto drained = [&](int code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return code;
+  };
   int rc;
   if ((rc = upload(ctx, ctx->pairs, all.data(), all.size())) != RT_OK)
-    return rc;
+    return drained(rc);
+  ctx->dev.pairs = ctx->pairs.ptr; // kept current after every reallocation
   if ((rc = upload(ctx, ctx->inst_trace, insts.data(), insts.size())) != RT_OK)
-    return rc;
+    return drained(rc);
+  ctx->dev.inst_trace = ctx->inst_trace.ptr;
   // per-instance shading records: matrices + the material resolved against the host copies of the
   // material tables (validated by rt_validate_materials for every instance a TLAS leaf names)
   std::vector<rt_dev_inst_shade> shade(n_inst);
@@ -281,7 +285,7 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
     }
   }
   if ((rc = upload(ctx, ctx->inst_shade, shade.data(), shade.size())) != RT_OK)
-    return rc;
+    return drained(rc);
   // the staging vector dies at return: finish the copies first
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->dev.pairs = ctx->pairs.ptr;
@@ -319,7 +323,8 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
   HIP_TRY(hipSetDevice(device_id));
   rt_ctx *ctx = new rt_ctx();
   ctx->device = device_id;
-  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  ctx->stream = ctx->own_stream;
   if (e == hipSuccess)
     e = ctx->counter.reserve(1);
   if (e == hipSuccess)
@@ -333,6 +338,10 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
   if (e == hipSuccess && ctx->cus == 0)
     e = hipErrorInvalidDevice;
   if (e != hipSuccess) {
+    ctx->counter.release();
+    ctx->queue.release();
+    if (ctx->own_stream)
+      (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return fail(RT_ERR_HIP, std::string("rt_create: ") + hipGetErrorString(e));
   }
@@ -362,11 +371,9 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->texels.release();
   ctx->counter.release();
   ctx->queue.release();
-  ctx->cold.release();
-  ctx->cold10.release();
-  ctx->wf_mem.release();
   ctx->accum_own.release();
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream)
+    (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return RT_OK;
 }
@@ -392,13 +399,18 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *sc) {
   if (!rt_validate_materials(sc, sc->instances, sc->instance_count, ctx->flat.inst_live, err))
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_upload_scene: " + err);
   ctx->blas_count = sc->blas_count;
+  // an error return must not leave copies from the caller's arrays queued (the caller may free them at once)
+  auto drained = [&](int code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return code;
+  };
   int rc;
   if ((rc = upload(ctx, ctx->tris, ctx->flat.tris.data(), ctx->flat.tris.size())) != RT_OK)
-    return rc;
+    return drained(rc);
   if ((rc = upload(ctx, ctx->shading, sc->tri_shading, sc->tri_capacity)) != RT_OK)
-    return rc;
+    return drained(rc);
   if ((rc = upload(ctx, ctx->texels, sc->texels, (size_t)sc->texel_bytes)) != RT_OK)
-    return rc;
+    return drained(rc);
   ctx->dev.tris = ctx->tris.ptr;
   ctx->dev.shading = ctx->shading.ptr;
   ctx->dev.texels = ctx->texels.ptr;
@@ -415,7 +427,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *sc) {
   ctx->material_counts.textures = ctx->h_textures.data();
   ctx->texel_bytes = sc->texel_bytes;
   if ((rc = upload_pairs_and_instances(ctx, sc->instances, sc->instance_count)) != RT_OK)
-    return rc;
+    return drained(rc);
   ctx->flat.tris.clear();
   ctx->flat.tris.shrink_to_fit(); // resident in HBM now
   ctx->have_scene = true;
@@ -429,15 +441,48 @@ int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances, uint32_t
   if (!ctx->have_scene)
     return fail(RT_ERR_NO_SCENE, "rt_update_instances: no scene uploaded");
   HIP_TRY(hipSetDevice(ctx->device));
+  // Validation works on the side: a rejected update leaves the scene that is on the device, and the host
+  // description of it (ctx->flat: stack depth, instance table), exactly as they were.
+  rt_flat_scene &f = ctx->flat;
+  std::vector<rt_dev_pair> old_pairs = std::move(f.tlas_pairs);
+  std::vector<rt_dev_inst> old_insts = std::move(f.insts);
+  std::vector<uint8_t> old_live = std::move(f.inst_live);
+  const uint32_t old_root = f.root_ref, old_depth = f.tlas_depth, old_stack = f.stack_needed;
   std::string err;
-  if (!rt_flatten_tlas(instances, instance_count, tlas_nodes, tlas_node_count, ctx->blas_count,
-                       ctx->flat, err))
+  bool ok = rt_flatten_tlas(instances, instance_count, tlas_nodes, tlas_node_count, ctx->blas_count, f, err) &&
+            rt_validate_materials(&ctx->material_counts, instances, instance_count, f.inst_live, err);
+  if (ok && f.stack_needed > RT_MAX_STACK) {
+    ok = false;
+    err = "scene needs a traversal stack of " + std::to_string(f.stack_needed) + " entries; the kernels hold " +
+          std::to_string(RT_MAX_STACK);
+  }
+  if (!ok) {
+    f.tlas_pairs = std::move(old_pairs), f.insts = std::move(old_insts), f.inst_live = std::move(old_live);
+    f.root_ref = old_root, f.tlas_depth = old_depth, f.stack_needed = old_stack;
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
-  if (!rt_validate_materials(&ctx->material_counts, instances, instance_count, ctx->flat.inst_live, err))
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_update_instances: " + err);
+  }
   // kernels in flight still read the old arrays
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return upload_pairs_and_instances(ctx, instances, instance_count);
+  // From here on device buffers may be reallocated: until the upload has finished there is no scene to render
+  // (a failure below — out of memory — leaves have_scene false, and rt_render refuses instead of reading freed memory).
+  ctx->have_scene = false;
+  const int rc = upload_pairs_and_instances(ctx, instances, instance_count);
+  if (rc != RT_OK)
+    return rc;
+  ctx->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_stream(rt_ctx *ctx, void *hip_stream) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_stream: NULL context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int rc = drain_events(ctx); // the timing events were recorded on the old stream
+  if (rc != RT_OK)
+    return rc;
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RT_OK;
 }
 
 int rt_set_camera(rt_ctx *ctx, const rt_camera_uniforms *camera) {
@@ -527,6 +572,11 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     pc.row_end = pc.image_height;
   if (pc.row_begin >= pc.row_end)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty row range");
+  // interleaved launches (rt_types.h): the stride counts 8-row groups, so the range starts on a group boundary and
+  // a stride beyond the number of groups in the image is a caller's mistake (8 * stride must not wrap either)
+  if (pc.row_group_stride > 1u && ((pc.row_begin & 7u) != 0u || pc.row_group_stride > pc.image_height / 8u + 1u))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: row_group_stride > 1 needs row_begin % 8 == 0 and a stride of at "
+                                         "most image_height / 8 + 1 groups");
   HIP_TRY(hipSetDevice(ctx->device));
   // Kernel choice when the caller set none (tools/bench_lowspp.py): the vote-scheduled persistent kernel, except
   // for a tiny scene rendered with a few short paths per pixel — the reference's live configuration, built-in
@@ -535,49 +585,17 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
   const uint32_t variant = !ctx->variant_auto ? ctx->variant
                            : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
-  const uint32_t kind = variant & 0xFFu;
-  const bool wavefront = kind == 4 && pc.max_depth > 0 && pc.max_depth <= 255 &&
-                         (uint64_t)pc.sqrt_spp * pc.sqrt_spp < (1u << 24);
-  if (wavefront) {
-    if (ctx->wf_w != pc.image_width || ctx->wf_h != pc.image_height || !ctx->wf_mem.ptr) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx->wf_mem.reserve(rt_wf_bytes(pc.image_width, pc.image_height)));
-      ctx->wf_w = pc.image_width, ctx->wf_h = pc.image_height;
-    }
-  }
-  if (kind == 7) {
-    if (!ctx->cold.ptr) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx->cold.reserve(rt_v7_cold_bytes(ctx->cus)));
-    }
-  }
-  if (kind == 10) {
-    if (ctx->flat.insts.size() > 0xFFFFu)
-      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel variant 10 packs the instance id into 16 bits");
-    if (!ctx->cold10.ptr) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx->cold10.reserve(rt_v10_cold_bytes(ctx->cus)));
-    }
-  }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  if (kind == 10) {
-    HIP_TRY(rt_launch_render_v10(variant | (ctx->regen_idle << 8), ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
-                                 reinterpret_cast<uint32_t *>(ctx->cold10.ptr), ctx->cus, ctx->stream));
-  } else if (kind == 7) {
-    HIP_TRY(rt_launch_render_v7(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                                ctx->queue.ptr, reinterpret_cast<uint32_t *>(ctx->cold.ptr), ctx->cus,
-                                effective_regen_idle(ctx, pc), ctx->stream));
-  } else if (wavefront) {
-    rt_wf_buffers wb = rt_wf_carve(ctx->wf_mem.ptr, pc.image_width, pc.image_height);
-    HIP_TRY(rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, wb,
-                                       ctx->wf_pair_min, ctx->wf_refill_min, ctx->wf_occ, ctx->cus, ctx->stream));
-  } else {
-    HIP_TRY(rt_launch_render(kind == 4 ? 2u : variant, ctx->dev, ctx->camera, pc, ctx->accum,
-                             ctx->counter.ptr, ctx->queue.ptr, effective_regen_idle(ctx, pc), ctx->cus, ctx->stream));
+  const hipError_t le = rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
+                                         ctx->queue.ptr, effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
+  if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent
+    ctx->free_events.push_back(ev);
+    return fail(RT_ERR_HIP, std::string("rt_render: launch failed: ") + hipGetErrorString(le));
   }
+  ctx->last_kernel = variant & 0xFFu;
   return end_timed(ctx, ev);
 }
 
@@ -594,8 +612,12 @@ int rt_trace_closest_device(rt_ctx *ctx, const void *device_rays, uint64_t n, vo
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  HIP_TRY(rt_launch_trace(ctx->dev, static_cast<const rt_ray *>(device_rays), n,
-                          static_cast<rt_hit *>(device_hits), aabb_mode, ctx->counter.ptr, ctx->stream));
+  const hipError_t le = rt_launch_trace(ctx->dev, static_cast<const rt_ray *>(device_rays), n,
+                                        static_cast<rt_hit *>(device_hits), aabb_mode, ctx->counter.ptr, ctx->stream);
+  if (le != hipSuccess) {
+    ctx->free_events.push_back(ev);
+    return fail(RT_ERR_HIP, std::string("rt_trace_closest_device: launch failed: ") + hipGetErrorString(le));
+  }
   return end_timed(ctx, ev);
 }
 
@@ -670,6 +692,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
   out->total_kernel_ms = ctx->total_ms;
   out->launches = ctx->launches;
   out->stack_depth_needed = ctx->flat.stack_needed;
+  out->last_kernel = ctx->last_kernel;
   out->device_bytes = ctx->pairs.count * sizeof(rt_dev_pair) + ctx->tris.count * sizeof(rt_dev_tri) +
                       ctx->inst_trace.count * sizeof(rt_dev_inst) +
                       ctx->inst_shade.count * sizeof(rt_dev_inst_shade) +
@@ -707,7 +730,11 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
   EventPair ev;
   if ((rc = begin_timed(ctx, ev)) != RT_OK)
     return rc;
-  HIP_TRY(rt_launch_probe_walk(ctx->dev, blocks, steps, loads, ctx->counter.ptr, ctx->stream));
+  const hipError_t le = rt_launch_probe_walk(ctx->dev, blocks, steps, loads, ctx->counter.ptr, ctx->stream);
+  if (le != hipSuccess) {
+    ctx->free_events.push_back(ev);
+    return fail(RT_ERR_HIP, std::string("rt_debug_probe_walk: launch failed: ") + hipGetErrorString(le));
+  }
   if ((rc = end_timed(ctx, ev)) != RT_OK)
     return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -799,18 +826,13 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
     ctx->variant_auto = true, ctx->variant = 8, ctx->regen_idle = 0;
     return RT_OK;
   }
-  if (!ctx || (variant & 0xFFu) > 10 || (variant & 0xFFu) == 9)
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: bad argument");
+  const uint32_t kernel = variant & 0xFFu;
+  if (!ctx || (kernel != 0 && kernel != 8))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: the library holds kernels 0 and 8");
   ctx->variant_auto = false;
-  // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: per-kernel experiment knobs (rt_kernels.hip)
-  ctx->variant = (variant & 0xFFu) == 4 ? 4u : (variant & 0xFFFF00FFu);
+  // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: schedule knobs of kernel 8 (rt_launch_render)
+  ctx->variant = variant & 0xFFFF00FFu;
   ctx->regen_idle = (variant >> 8) & 0xFFu; // 0: chosen by scene size (effective_regen_idle)
-  if ((variant >> 8) & 0xFFu)
-    ctx->wf_refill_min = (variant >> 8) & 0xFFu;
-  if ((variant & 0xFFu) == 4 && ((variant >> 16) & 0xFFu)) // variant 4: bits 16-23 = pair_min
-    ctx->wf_pair_min = (variant >> 16) & 0xFFu;
-  if ((variant & 0xFFu) == 4 && (variant >> 24)) // bits 24.. = waves/SIMD build
-    ctx->wf_occ = variant >> 24;
   return RT_OK;
 }
 

@@ -49,19 +49,6 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
                             uint32_t cus, hipStream_t stream);
 
-// rt_render_v10.hip: pooled scheduling (128 paths per wave, traversal state in LDS); d_cold holds rt_v10_cold_bytes(cus)
-size_t rt_v10_cold_bytes(uint32_t cus);
-hipError_t rt_launch_render_v10(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
-                                const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
-                                uint32_t *d_queue, uint32_t *d_cold, uint32_t cus, hipStream_t stream);
-
-// rt_render_v7.hip: low-register vote-scheduled kernel; d_cold holds rt_v7_cold_bytes(cus) bytes
-size_t rt_v7_cold_bytes(uint32_t cus);
-hipError_t rt_launch_render_v7(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
-                               const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
-                               uint32_t *d_queue, uint32_t *d_cold, uint32_t cus, uint32_t regen_idle,
-                               hipStream_t stream);
-
 hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_t steps, uint32_t loads,
                                 unsigned long long *d_out, hipStream_t stream);
 

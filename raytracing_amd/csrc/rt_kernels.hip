@@ -2,8 +2,12 @@
 //
 //   k_trace_closest : intersect_tlas over a ray batch        (TLAS.slang:14-67)
 //   k_render_v0     : compute_main, one lane per pixel       (RayTracing.slang:62-181)
-//   k_render_v1     : the same arithmetic per pixel, scheduled as persistent
-//                     wave64s that regenerate paths and pull pixels from a queue
+//   k_render_v8     : the same arithmetic per pixel, scheduled as persistent wave64s with path regeneration, a
+//                     resumable per-lane traversal, vote scheduling and joined pair / leaf steps (the default)
+//
+// The kernels measured and dropped in round 1 (variants 1-7 and 10: persistent without resumable traversal, LDS
+// node cache, wavefront pipeline, register-top stack, HBM path state, pooled scheduling) live in
+// experiments/r01_variants/ and are not part of the library.
 //
 // Bit-exactness contract with the oracle: fp32, no FMA contraction (file-wide
 // pragma + -ffp-contract=off), IEEE divide/sqrt (hipcc default), explicit
@@ -93,110 +97,13 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
 }
 
 // ---------------------------------------------------------------------------
-// k_render_v1: persistent wave64s with path regeneration.  Per pixel the
-// arithmetic and the RNG draw order are those of k_render_v0 (so the image is
-// the same bit for bit); what changes is the schedule:
-//   * a lane whose path ended (sky, light, depth) starts its pixel's next
-//     sample at once instead of idling until the longest path of the wave ends;
-//   * a lane whose pixel is finished pulls the next pixel from a global queue
-//     (one wave-aggregated atomic per refill), in 8x8-tile order so that the
-//     lanes of a wave keep working on neighbouring pixels;
-//   * the grid is sized to the chip (resident blocks only), every lane runs
-//     until the queue is empty, every wave leaves when its 64 lanes are done.
-// ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(RT_BLOCK)
-    k_render_v1(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
-                float4 *__restrict__ accum, unsigned long long *ray_counter,
-                uint32_t *__restrict__ queue) {
-  __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
-  RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t rows = rt_virtual_rows(pc);
-  const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
-  const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
-  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
-  const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
-
-  bool alive = true, have_pixel = false, have_path = false;
-  uint32_t x = 0, y = 0, sample = 0, depth = 0, traced = 0;
-  Rng rng = make_rng(pc, 0, 0);
-  V3 radiance = v3(0.f, 0.f, 0.f);
-  Path p;
-  p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
-
-  while (true) {
-    // ---- refill: pixels for lanes that have none ----
-    while (true) {
-      const bool need = alive && !have_pixel;
-      const unsigned long long mask = __ballot(need);
-      if (mask == 0ull)
-        break;
-      const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-      uint32_t base = 0;
-      if (lane == leader)
-        base = atomicAdd(queue, (uint32_t)__popcll(mask));
-      base = __shfl(base, (int)leader, 64);
-      if (need) {
-        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (slot >= total_slots) {
-          alive = false;
-        } else {
-          const uint32_t tile = slot >> 6, in = slot & 63u;
-          x = (tile % tiles_x) * 8u + (in & 7u);
-          y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
-          if (x < pc.image_width && y < pc.row_end) { // else: edge padding, fetch again
-            have_pixel = true;
-            have_path = false;
-            sample = 0;
-            rng = make_rng(pc, x, y);
-            radiance = v3(0.f, 0.f, 0.f);
-          }
-        }
-      }
-    }
-    if (__ballot(alive) == 0ull)
-      break;
-    // ---- regenerate: next camera ray of the lane's pixel ----
-    if (have_pixel && !have_path) {
-      rng.sample = pc.frame_index * spp + sample;
-      rng.set_slot(0);
-      camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
-      depth = 0;
-      have_path = true;
-    }
-    // ---- one bounce for every lane that has a path ----
-    bool path_ends = have_path;
-    if (have_path && depth < pc.max_depth) {
-      rng.set_slot(depth + 1);
-      Hit hit;
-      const bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
-      ++traced;
-      const bool scattered = shade(sc, any, hit, rng, p);
-      ++depth;
-      path_ends = !scattered || depth >= pc.max_depth;
-    }
-    if (have_path && path_ends) {
-      radiance = radiance + p.sample_radiance; // RayTracing.slang:170
-      have_path = false;
-      if (++sample == spp) {
-        accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
-        have_pixel = false;
-      }
-    }
-  }
-  count_rays(ray_counter, traced);
-}
-
-// ---------------------------------------------------------------------------
-// k_render_v2: persistent wave64s, path regeneration AND resumable traversal.
-// Profiling k_render_v1 (profiles/r01_v1_persistent) showed 19 % VALU lane
-// utilisation: a wave waits for its longest ray while sky rays finish after a
-// handful of nodes.  Here the traversal itself is a per-lane state machine
-// (reference, stack pointer, object-space ray, closest hit live in registers /
-// LDS between steps): the wave runs traversal steps until `regen_idle` lanes
-// have finished their ray (or none is traversing any more); then it shades
-// those lanes, regenerates their next ray (next bounce, next sample or
-// next pixel from the queue) and resumes — the unfinished lanes simply carry
+// k_render_v8: persistent wave64s, path regeneration, resumable traversal, vote scheduling with joined steps.
+// A one-lane-per-pixel kernel waits for its longest ray while sky rays finish after a handful of nodes (13 %
+// VALU lane utilisation, profiles/r01_v0_baseline).  Here the grid is sized to the chip, pixels come from a global
+// queue in 8x8 tiles, and the traversal itself is a per-lane state machine (reference, stack pointer, object-space
+// ray, closest hit live in registers / LDS between steps): the wave runs traversal steps until `regen_idle` lanes
+// have finished their ray (or none is traversing any more); then it shades those lanes, regenerates their next
+// ray (next bounce, next sample or next pixel from the queue) and resumes — the unfinished lanes simply carry
 // on.  Per pixel the sequence of arithmetic and RNG draws is unchanged.
 // ---------------------------------------------------------------------------
 #ifndef RT_V8_MINW
@@ -221,33 +128,14 @@ __device__ unsigned long long g_v2_stats[32];
 #endif
 enum : uint32_t { ST_FETCH = 0, ST_NEWPATH = 1, ST_TRAVERSE = 2, ST_SHADE = 3, ST_DONE = 4 };
 
-//
-// NCACHE > 0 (variant 3): the first NCACHE pair records of the scene — the top
-// of the TLAS and of the BLASes, which rt_upload_scene numbers first in
-// breadth-first order — are copied into LDS once per workgroup; every ray
-// walks through them, so about half of all node visits are served by
-// ds_read_b128 (LDS latency, no TA/TD/L1 traffic) instead of four divergent
-// 16-byte global gathers.  One 1024-thread workgroup per CU then owns the
-// whole 160 KiB of LDS: 16 stack entries per lane + 1536 cached records.
-template <int MODE, int MINW, int BLOCK, int NLDS, int NCACHE, int SCHED>
+template <int MODE, int MINW, int BLOCK, int NLDS>
 __global__ void __launch_bounds__(BLOCK, MINW)
-    k_render_v2(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
+    k_render_v8(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc,
                 float4 *__restrict__ accum, unsigned long long *ray_counter,
-                uint32_t *__restrict__ queue, uint32_t regen_idle, uint32_t nbands_arg, uint32_t sched_arg) {
+                uint32_t *__restrict__ queue, uint32_t regen_idle, uint32_t sched_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw;                                                  // [NLDS][BLOCK]
   typedef float f4v __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) const f4v *lds_f4_ptr; // typed: ds_read_b128, never flat
-  const lds_f4_ptr lds_cache = (lds_f4_ptr)(lds_raw + NLDS * BLOCK); // [NCACHE][4]
-  uint32_t ncache = 0;
-  if (NCACHE > 0) {
-    ncache = sc.cache_pairs < (uint32_t)NCACHE ? sc.cache_pairs : (uint32_t)NCACHE;
-    float4 *dst = reinterpret_cast<float4 *>(lds_raw + NLDS * BLOCK);
-    const float4 *src = reinterpret_cast<const float4 *>(sc.pairs);
-    for (uint32_t i = threadIdx.x; i < ncache * 4u; i += BLOCK)
-      dst[i] = src[i];
-    __syncthreads();
-  }
   RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t rows = rt_virtual_rows(pc);
@@ -255,11 +143,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   const uint32_t total_slots = tiles_x * ((rows + 7u) >> 3) * 64u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
-
-  // queue bands (wave-uniform)
-  const uint32_t nbands = nbands_arg == 0 ? 1u : nbands_arg;
-  const uint32_t band_slots = (((total_slots >> 6) + nbands - 1u) / nbands) << 6; // whole tiles
-  uint32_t cur_band = blockIdx.x % nbands, bands_tried = 0;
 
   uint32_t state = ST_FETCH;
   uint32_t x = 0, y = 0, sample = 0, depth = 0, traced = 0;
@@ -269,7 +152,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   p.o = p.d = p.attenuation = p.sample_radiance = v3(0.f, 0.f, 0.f);
   // traversal state of the lane's current ray
   uint32_t ref = RT_REF_NONE, cur_inst = 0;
-  uint32_t top = RT_REF_NONE; // SCHED 2: top stack entry (StackT::push_top / pop_top)
   // the ray in the space it is being traversed in (prep_space)
   V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
   bool fast = false;
@@ -308,36 +190,29 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     V2_T(ta1);
     V2_ACC(0, ta0, ta1);
     V2_CNT(1, state == ST_FETCH);
-    // ---- (2) lanes without a pixel: pull from the queues (wave-uniform loop) ----
-    // Eight queues, one per group of workgroups that share an XCD (blockIdx % 8
-    // labels the group): each covers one contiguous band of 8x8 tiles, so an
-    // XCD's 4 MiB L2 sees the rays of one region of the image and of the BVH.
-    // A wave whose band is finished moves on to the next band (work stealing).
+    // ---- (2) lanes without a pixel: pull from the queue (wave-uniform loop) ----
+    // One global queue of 8x8 tiles.  (Per-XCD queue bands, so that an XCD's L2 sees one region of the image,
+    // measured 8 % slower twice in round 1: the bands finish at different times.)
     while (true) {
       const bool need = state == ST_FETCH;
       const unsigned long long mask = __ballot(need);
       if (mask == 0ull)
         break;
-      if (bands_tried == nbands) { // every band is empty
+      const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+      uint32_t base = 0;
+      if (lane == leader)
+        base = atomicAdd(queue, (uint32_t)__popcll(mask));
+      base = __shfl(base, (int)leader, 64);
+      if (base >= total_slots) { // the queue is exhausted for everybody
         if (need)
           state = ST_DONE;
         break;
       }
-      const uint32_t band_lo = cur_band * band_slots;
-      const uint32_t band_hi = band_lo + band_slots < total_slots ? band_lo + band_slots : total_slots;
-      const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-      uint32_t base = 0;
-      if (lane == leader)
-        base = atomicAdd(queue + cur_band, (uint32_t)__popcll(mask));
-      base = __shfl(base, (int)leader, 64) + band_lo;
-      if (base >= band_hi) { // this band is exhausted for everybody: steal from the next one
-        cur_band = cur_band + 1u == nbands ? 0u : cur_band + 1u;
-        ++bands_tried;
-        continue;
-      }
       if (need) {
         const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < band_hi) { // else: retry on the next iteration (band just ran out)
+        if (slot >= total_slots) {
+          state = ST_DONE;
+        } else {
           const uint32_t tile = slot >> 6, in = slot & 63u;
           x = (tile % tiles_x) * 8u + (in & 7u);
           y = rt_row(pc, (tile / tiles_x) * 8u + (in >> 3));
@@ -382,7 +257,6 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       any = false;
       cur_inst = 0;
       st.sp = 0;
-      top = RT_REF_NONE;
       state = ref == RT_REF_NONE ? ST_SHADE : ST_TRAVERSE;
     }
     V2_T(ta4);
@@ -390,288 +264,23 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     const uint32_t n_done = (uint32_t)__popcll(__ballot(state == ST_DONE));
     (void)n_done;
     // ---- (4) traversal steps while enough lanes are traversing ----
-    if (SCHED == 2) {
-      // Variant 6 = the vote scheduling of variant 5 (below) with the stack top in a register: no pop
-      // section, no pop loop; a sentinel is handled as an instance-space step.
-      // Vote scheduling: each wave iteration runs ONE kind of step —
-      // the one most lanes are waiting for — so the instruction stream of an
-      // iteration is one section at good lane occupancy instead of every section
-      // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
-      // the other kinds wait; per lane the sequence of steps is unchanged.
-      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 3u;
-      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 6u;
-      while (true) {
-        const uint32_t kind =
-            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
-        const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
-        const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
-        const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
-        if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
-          break;
-        const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
-        V2_T(tb0);
-        if (s1 >= s2 && s1 >= s3) {
-          V2_CNT(4, kind == 1u);
-          if (kind == 1u) {
-            float4 qx, qy, qz, qr;
-            if (NCACHE > 0 && ref < ncache) {
-              const lds_f4_ptr q = lds_cache + ref * 4u;
-              const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-              qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
-              qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
-              asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
-            } else {
-              const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-              qx = q[0], qy = q[1], qz = q[2];
-              const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
-              qr = make_float4(r2.x, r2.y, 0.f, 0.f);
-            }
-            float dist1, dist2;
-            if (fast) {
-              slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
-            } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
-              float4 lo0, hi0, lo1, hi1;
-              unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
-              dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-              dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-            }
-            uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
-            if (dist1 > dist2) {
-              float tf = dist1;
-              dist1 = dist2;
-              dist2 = tf;
-              uint32_t tc = c1;
-              c1 = c2;
-              c2 = tc;
-            }
-            if (dist1 == kMiss) {
-              ref = st.pop_top(top);
-              if (ref == RT_REF_NONE)
-                state = ST_SHADE;
-            } else {
-              if (dist2 != kMiss)
-                st.push_top(top, c2);
-              ref = c1;
-            }
-          }
-          V2_T(tb1);
-          V2_ACC(4, tb0, tb1);
-        } else if (s3 >= s2) {
-          V2_CNT(6, kind == 3u);
-          if (kind == 3u) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
-            const uint32_t k = ref & 0x7FFFFFFFu;
-            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
-            float4 t0 = q[0], t1 = q[1], t2 = q[2];
-            const bool last = __float_as_uint(t1.w) != 0u; // last triangle of the leaf
-            V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
-               edge_2 = v3(t2.x, t2.y, t2.z);
-            V3 h = cross(cd, edge_2);
-            float a = dot(edge_1, h);
-            if (!(a > -kEpsilon && a < kEpsilon)) {
-              float f = 1.f / a;
-              V3 s = co - v0;
-              float u = f * dot(s, h);
-              if (!(u < 0 || u > 1)) {
-                V3 qq = cross(s, edge_1);
-                float v = f * dot(cd, qq);
-                if (!(v < 0 || u + v > 1)) {
-                  float t = f * dot(edge_2, qq);
-                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
-                    closest = t;
-                    any = true;
-                    hit.u = u;
-                    hit.v = v;
-                    hit.tri = __float_as_uint(t0.w);
-                    hit.inst = cur_inst;
-                  }
-                }
-              }
-            }
-            if (last) {
-              ref = st.pop_top(top);
-              if (ref == RT_REF_NONE)
-                state = ST_SHADE;
-            } else {
-              ref = ref + 1u;
-            }
-          }
-          V2_T(tb1);
-          V2_ACC(6, tb0, tb1);
-        } else {
-          V2_CNT(5, kind == 2u);
-          if (kind == 2u && ref == RT_REF_SENTINEL) { // the instance's BLAS is finished: back to world space
-            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-            ref = st.pop_top(top);
-            if (ref == RT_REF_NONE)
-              state = ST_SHADE;
-          } else if (kind == 2u) {
-            cur_inst = ref & 0x3FFFFFFFu;
-            const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
-            float4 a = q[0], b = q[1], c = q[2], e = q[3];
-            V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
-               c3 = v3(e.x, e.y, e.z);
-            co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-            st.push_top(top, RT_REF_SENTINEL);
-            ref = __float_as_uint(a.w);
-          }
-          V2_T(tb1);
-          V2_ACC(5, tb0, tb1);
-        }
-      }
-    } else if (SCHED == 1) {
-      // Vote scheduling (variant 5): each wave iteration runs ONE kind of step —
-      // the one most lanes are waiting for — so the instruction stream of an
-      // iteration is one section at good lane occupancy instead of every section
-      // at poor occupancy.  A BLAS leaf advances one triangle per step.  Lanes of
-      // the other kinds wait; per lane the sequence of steps is unchanged.
-      // Default weights pair : leaf : instance = 2 : 4 : 5, measured (tools/compare_vote.sh, tools/sweep_configs.sh):
-      // against the first choice 1 : 3 : 6 that is +1 % on C3 and +3 .. 9 % on C1 / C2 / C4 / C5.
-      const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 2u;
-      const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 4u;
-      const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 5u;
-      while (true) {
-        const uint32_t kind =
-            state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
-        const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
-        const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
-        const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
-        if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
-          break;
-        const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
-        bool do_pop = false;
-        V2_T(tb0);
-        if (s1 >= s2 && s1 >= s3) {
-          V2_CNT(4, kind == 1u);
-          if (kind == 1u) {
-            float4 qx, qy, qz, qr;
-            if (NCACHE > 0 && ref < ncache) {
-              const lds_f4_ptr q = lds_cache + ref * 4u;
-              const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-              qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
-              qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
-              asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
-            } else {
-              const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-              qx = q[0], qy = q[1], qz = q[2];
-              const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
-              qr = make_float4(r2.x, r2.y, 0.f, 0.f);
-            }
-            float dist1, dist2;
-            if (fast) {
-              slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
-            } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
-              float4 lo0, hi0, lo1, hi1;
-              unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
-              dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-              dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-            }
-            uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
-            if (dist1 > dist2) {
-              float tf = dist1;
-              dist1 = dist2;
-              dist2 = tf;
-              uint32_t tc = c1;
-              c1 = c2;
-              c2 = tc;
-            }
-            if (dist1 == kMiss) {
-              do_pop = true;
-            } else {
-              if (dist2 != kMiss)
-                st.push(c2);
-              ref = c1;
-            }
-          }
-          V2_T(tb1);
-          V2_ACC(4, tb0, tb1);
-        } else if (s3 >= s2) {
-          V2_CNT(6, kind == 3u);
-          if (kind == 3u) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
-            const uint32_t k = ref & 0x7FFFFFFFu;
-            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
-            float4 t0 = q[0], t1 = q[1], t2 = q[2];
-            if (__float_as_uint(t1.w))
-              do_pop = true; // last triangle of the leaf
-            else
-              ref = ref + 1u;
-            V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
-               edge_2 = v3(t2.x, t2.y, t2.z);
-            V3 h = cross(cd, edge_2);
-            float a = dot(edge_1, h);
-            if (!(a > -kEpsilon && a < kEpsilon)) {
-              float f = 1.f / a;
-              V3 s = co - v0;
-              float u = f * dot(s, h);
-              if (!(u < 0 || u > 1)) {
-                V3 qq = cross(s, edge_1);
-                float v = f * dot(cd, qq);
-                if (!(v < 0 || u + v > 1)) {
-                  float t = f * dot(edge_2, qq);
-                  if (!(t < kEpsilon || !(0.0001f <= t && t <= closest))) {
-                    closest = t;
-                    any = true;
-                    hit.u = u;
-                    hit.v = v;
-                    hit.tri = __float_as_uint(t0.w);
-                    hit.inst = cur_inst;
-                  }
-                }
-              }
-            }
-          }
-          V2_T(tb1);
-          V2_ACC(6, tb0, tb1);
-        } else {
-          V2_CNT(5, kind == 2u);
-          if (kind == 2u) {
-            cur_inst = ref & 0x3FFFFFFFu;
-            const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
-            float4 a = q[0], b = q[1], c = q[2], e = q[3];
-            V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
-               c3 = v3(e.x, e.y, e.z);
-            co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-            st.push(RT_REF_SENTINEL);
-            ref = __float_as_uint(a.w);
-          }
-          V2_T(tb1);
-          V2_ACC(5, tb0, tb1);
-        }
-        V2_T(tb3);
-        V2_CNT(7, do_pop);
-        if (do_pop) {
-          while (true) {
-            if (st.sp == 0) {
-              state = ST_SHADE;
-              break;
-            }
-            ref = st.pop();
-            if (ref != RT_REF_SENTINEL)
-              break;
-            co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-          }
-        }
-        V2_T(tb4);
-        V2_ACC(7, tb3, tb4);
-      }
-    } else if (SCHED == 3) {
-      // Variant 8 = the vote scheduling of variant 5 with JOINED pair and leaf steps.  With one-triangle
-      // leaves (the reference's SAH builder makes almost only those) a leaf iteration of variant 5 is one
-      // memory round trip for a dozen lanes.  Here an iteration that the vote gives to the pair lanes also
+    {
+      // Vote scheduling: each wave iteration runs ONE kind of step — the one most lanes are waiting for (weighted) —
+      // so the instruction stream of an iteration is one section at good lane occupancy instead of every section
+      // at poor occupancy.  A BLAS leaf advances one triangle per step.  Pair and leaf steps are JOINED: with
+      // one-triangle leaves (the reference's SAH builder makes almost only those) a leaf iteration of its own is one
+      // memory round trip for a dozen lanes, so an iteration that the vote gives to the pair lanes also
       // serves the leaf lanes when at least `join_min` of them wait (and the other way round): the loads of
       // both kinds are issued together, so the wave pays one round trip, then the triangle section and the
       // pair section run one after the other.  Per lane the sequence of steps is unchanged.
       // Default weights pair : leaf : instance = 1 : 2 : 3 and join threshold 8 lanes, measured (tools/sweep_v8.sh,
-      // sweep_v8b.sh, compare_v8.sh): +2 % over variant 5's 2 : 4 : 5 here, where most leaf steps ride along anyway.
+      // sweep_v8b.sh, compare_v8.sh).
       const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
       const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
       const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 3u;
       const uint32_t join_code = (sched_arg >> 12) & 7u;
       const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
                               : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
-      const uint64_t tri_delta = (uint64_t)(reinterpret_cast<const char *>(sc.tris) - reinterpret_cast<const char *>(sc.pairs));
       // `any` and `fast` as per-lane integers inside the step loop: as bools they live in scalar lane masks, and
       // every conditional update costs three scalar instructions where it merges, plus three per loop iteration
       uint32_t anyv = any ? 1u : 0u, fastv = fast ? 1u : 0u;
@@ -825,125 +434,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         }
       }
       any = anyv != 0u, fast = fastv != 0u;
-    } else
-    do {
-      // one step per traversing lane: 1 = interior pair, 2 = TLAS leaf (enter an instance), 3 = BLAS leaf
-      const uint32_t kind =
-          state != ST_TRAVERSE ? 0u : !(ref & RT_REF_LEAF) ? 1u : (ref & RT_REF_INST) ? 2u : 3u;
-      bool do_pop = false;
-      V2_T(tb0);
-      V2_CNT(4, kind == 1u);
-      if (kind == 1u) {
-        float4 qx, qy, qz, qr;
-        if (NCACHE > 0 && ref < ncache) {
-          const lds_f4_ptr q = lds_cache + ref * 4u;
-          const f4v a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-          qx = make_float4(a0.x, a0.y, a0.z, a0.w), qy = make_float4(a1.x, a1.y, a1.z, a1.w);
-          qz = make_float4(a2.x, a2.y, a2.z, a2.w), qr = make_float4(a3.x, a3.y, a3.z, a3.w);
-          asm volatile("" : "+v"(qr.x)); // keeps the optimiser from merging these with the global loads into flat loads
-        } else {
-          const float4 *q = reinterpret_cast<const float4 *>(sc.pairs + ref);
-          qx = q[0], qy = q[1], qz = q[2];
-          const float2 r2 = *reinterpret_cast<const float2 *>(q + 3);
-          qr = make_float4(r2.x, r2.y, 0.f, 0.f);
-        }
-        float dist1, dist2;
-        if (fast) {
-          slab_pair_fast<MODE>(co, cd, cinv, qx, qy, qz, closest, dist1, dist2);
-        } else { // the reference's formulation, for rays / scenes outside the fast path's preconditions
-          float4 lo0, hi0, lo1, hi1;
-          unpack_pair(qx, qy, qz, qr, lo0, hi0, lo1, hi1);
-          dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
-          dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
-        }
-        uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
-        if (dist1 > dist2) {
-          float tf = dist1;
-          dist1 = dist2;
-          dist2 = tf;
-          uint32_t tc = c1;
-          c1 = c2;
-          c2 = tc;
-        }
-        if (dist1 == kMiss) {
-          do_pop = true;
-        } else {
-          if (dist2 != kMiss)
-            st.push(c2);
-          ref = c1;
-        }
-      }
-      V2_T(tb1);
-      V2_ACC(4, tb0, tb1);
-      V2_CNT(5, kind == 2u);
-      if (kind == 2u) {
-        cur_inst = ref & 0x3FFFFFFFu;
-        const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
-        float4 a = q[0], b = q[1], c = q[2], e = q[3];
-        V3 c0 = v3(a.x, a.y, a.z), c1 = v3(b.x, b.y, b.z), c2 = v3(c.x, c.y, c.z),
-           c3 = v3(e.x, e.y, e.z);
-        co = mul_cols(c0, c1, c2, c3, p.o, 1.f), cd = mul_cols(c0, c1, c2, c3, p.d, 0.f);
-            prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-        st.push(RT_REF_SENTINEL);
-        ref = __float_as_uint(a.w);
-      }
-      V2_T(tb2);
-      V2_ACC(5, tb1, tb2);
-      if (kind == 3u) {
-        uint32_t k = ref & 0x7FFFFFFFu;
-        uint32_t last;
-        do {
-          V2_CNT(6, true);
-          const float4 *q = reinterpret_cast<const float4 *>(sc.tris + k);
-          float4 t0 = q[0], t1 = q[1], t2 = q[2];
-          last = __float_as_uint(t1.w);
-          ++k;
-          V3 v0 = v3(t0.x, t0.y, t0.z), edge_1 = v3(t1.x, t1.y, t1.z),
-             edge_2 = v3(t2.x, t2.y, t2.z);
-          V3 h = cross(cd, edge_2);
-          float a = dot(edge_1, h);
-          if (a > -kEpsilon && a < kEpsilon)
-            continue;
-          float f = 1.f / a;
-          V3 s = co - v0;
-          float u = f * dot(s, h);
-          if (u < 0 || u > 1)
-            continue;
-          V3 qq = cross(s, edge_1);
-          float v = f * dot(cd, qq);
-          if (v < 0 || u + v > 1)
-            continue;
-          float t = f * dot(edge_2, qq);
-          if (t < kEpsilon || !(0.0001f <= t && t <= closest))
-            continue;
-          closest = t;
-          any = true;
-          hit.u = u;
-          hit.v = v;
-          hit.tri = __float_as_uint(t0.w);
-          hit.inst = cur_inst;
-        } while (!last);
-        do_pop = true;
-      }
-      V2_T(tb3);
-      V2_ACC(6, tb2, tb3);
-      V2_CNT(7, do_pop);
-      if (do_pop) {
-        while (true) {
-          if (st.sp == 0) {
-            state = ST_SHADE;
-            break;
-          }
-          ref = st.pop();
-          if (ref != RT_REF_SENTINEL)
-            break;
-          co = p.o, cd = p.d, prep_space<MODE>(co, cd, scene_ok, cinv, fast);
-        }
-      }
-      V2_T(tb4);
-      V2_ACC(7, tb3, tb4);
-    } while (__ballot(state == ST_TRAVERSE) != 0ull &&
-             (uint32_t)__popcll(__ballot(state == ST_SHADE)) < regen_idle);
+    }
   }
 #ifdef RT_V2_STATS
   if (lane == 0) {
@@ -1081,20 +572,8 @@ hipError_t rt_launch_trace(const rt_dev_scene &sc, const rt_ray *d_rays, uint64_
   return hipGetLastError();
 }
 
-// hipFuncSetAttribute is per device: remember per (device, attribute group) whether it was done.
-static std::atomic<uint64_t> g_attr_done[2];
-static bool attr_done_on_this_device(int group) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  return dev >= 0 && dev < 64 && ((g_attr_done[group].load() >> dev) & 1ull);
-}
-static void mark_attr_done_on_this_device(int group) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64)
-    g_attr_done[group].fetch_or(1ull << dev);
-}
-
+// variant: low byte 0 = k_render_v0, 8 = k_render_v8; for 8, bits 16..27 = vote weights (pair, leaf, instance; 0 =
+// default), bits 28..30 = join threshold code, bit 31 = never take the fast slab path (test aid).
 hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                             const rt_render_params &pc, float *d_accum,
                             unsigned long long *d_counter, uint32_t *d_queue, uint32_t regen_idle,
@@ -1102,120 +581,43 @@ hipError_t rt_launch_render(uint32_t variant, const rt_dev_scene &sc, const rt_c
   uint32_t rows = rt_virtual_rows(pc);
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  if ((variant & 0xFFu) == 0) {
+  const uint32_t kernel = variant & 0xFFu;
+  if (kernel == 0) {
     uint32_t tiles = ((pc.image_width + 15u) >> 4) * ((rows + 15u) >> 4);
     hipLaunchKernelGGL(k_render_v0, dim3(tiles), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
                        reinterpret_cast<float4 *>(d_accum), d_counter);
     return hipGetLastError();
   }
-  // persistent grid: only as many blocks as the chip holds at once (cus = compute units of the device)
-  if (cus == 0)
+  if (kernel != 8 || cus == 0)
     return hipErrorInvalidValue;
+  // persistent grid: only as many blocks as the chip holds at once (cus = compute units of the device, 4 SIMDs each)
   const uint64_t slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
-  auto blocks_for = [&](uint32_t waves_per_simd, uint32_t block) { // 4 SIMDs per CU
-    uint64_t resident = (uint64_t)cus * (waves_per_simd * 4u / (block / 64u));
-    uint64_t need = (slots + block - 1) / block;
-    return (uint32_t)(need < resident ? need : resident);
-  };
-  uint32_t blocks = blocks_for((variant & 0xFFu) == 8 ? RT_V8_MINW : 4, RT_BLOCK);
-  // experiment knobs: variant 2/3 bits 24..30 = pixel-queue bands (8 = one per XCD; measured slower);
-  // variants 5/6 bits 16..27 = vote weights (pair, leaf, instance); bit 31 = never take the fast slab path
-  const uint32_t kernel = variant & 0xFFu;
-  const bool vote = kernel == 5 || kernel == 6 || kernel == 8;
-  const uint32_t nbands = (!vote && ((variant >> 24) & 0x7Fu)) ? ((variant >> 24) & 0x7Fu) : 1u;
-  // variant 8 bits 28..30 = join threshold code (k_render_v2, SCHED 3)
-  const uint32_t sched = (vote ? (variant >> 16) & 0xFFFu : 0u) | ((variant >> 31) ? 0x8000u : 0u) |
-                         (kernel == 8 ? ((variant >> 28) & 7u) << 12 : 0u);
-  hipError_t e = hipMemsetAsync(d_queue, 0, 64 * sizeof(uint32_t), stream);
+  const uint64_t resident = (uint64_t)cus * (RT_V8_MINW * 4u / (RT_BLOCK / 64u));
+  const uint64_t need = (slots + RT_BLOCK - 1) / RT_BLOCK;
+  const uint32_t blocks = (uint32_t)(need < resident ? need : resident);
+  const uint32_t sched = ((variant >> 16) & 0xFFFu) | ((variant >> 31) ? 0x8000u : 0u) | (((variant >> 28) & 7u) << 12);
+  hipError_t e = hipMemsetAsync(d_queue, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess)
     return e;
-  if ((variant & 0xFFu) == 1) {
-    hipLaunchKernelGGL(k_render_v1, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc,
-                       reinterpret_cast<float4 *>(d_accum), d_counter, d_queue);
-  } else if (kernel == 2 || vote) {
-    // experiment knob (variants 5/6, bits 28..30): run at 1..3 waves/SIMD instead of 4 by padding the
-    // workgroup's LDS allocation — measures how much the kernel gains from each extra resident wave
-    size_t lds_bytes = RT_LDS_STACK * RT_BLOCK * 4;
-    const uint32_t occ = (kernel == 5 || kernel == 6) ? (variant >> 28) & 7u : 0u;
-    if (occ >= 1 && occ <= 3) {
-      lds_bytes = (size_t)(160 * 1024 / occ) - 512;
-      blocks = blocks_for(occ, RT_BLOCK);
-      if (!attr_done_on_this_device(0)) {
-        const void *fns[] = {reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
-                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, RT_BLOCK, RT_LDS_STACK, 0, 2>),
-                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, RT_BLOCK, RT_LDS_STACK, 0, 1>),
-                             reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, RT_BLOCK, RT_LDS_STACK, 0, 2>)};
-        for (const void *fn : fns) {
-          hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          if (ea != hipSuccess)
-            return ea;
-        }
-        mark_attr_done_on_this_device(0);
-      }
-    }
-#define RT_V2S(MODE, S)                                                                            \
-  hipLaunchKernelGGL((k_render_v2<MODE, (S == 3 ? RT_V8_MINW : 4), RT_BLOCK, RT_LDS_STACK, 0, S>), dim3(blocks),           \
-                     dim3(RT_BLOCK), lds_bytes, stream, sc, cam, pc,                               \
-                     reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands,  \
-                     sched)
-    const bool rcp = pc.aabb_mode == RT_AABB_RCP;
-    if (kernel == 8) {
-      if (rcp)
-        RT_V2S(RT_AABB_RCP, 3);
-      else
-        RT_V2S(RT_AABB_DIV, 3);
-    } else if (kernel == 6) {
-      if (rcp)
-        RT_V2S(RT_AABB_RCP, 2);
-      else
-        RT_V2S(RT_AABB_DIV, 2);
-    } else if (kernel == 5) {
-      if (rcp)
-        RT_V2S(RT_AABB_RCP, 1);
-      else
-        RT_V2S(RT_AABB_DIV, 1);
-    } else {
-      if (rcp)
-        RT_V2S(RT_AABB_RCP, 0);
-      else
-        RT_V2S(RT_AABB_DIV, 0);
-    }
-#undef RT_V2S
-  } else {
-    // variant 3: one 1024-thread workgroup per CU owning all 160 KiB of LDS
-    constexpr int B3 = 1024, NL3 = 16, NC3 = 1536;
-    constexpr size_t lds3 = (size_t)NL3 * B3 * 4 + (size_t)NC3 * 64;
-    static_assert(lds3 <= 160 * 1024, "variant 3 LDS budget");
-    if (!attr_done_on_this_device(1)) {
-      hipError_t ea = hipFuncSetAttribute(
-          reinterpret_cast<const void *>(&k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3, 0>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      if (ea == hipSuccess)
-        ea = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3, 0>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      if (ea != hipSuccess)
-        return ea;
-      mark_attr_done_on_this_device(1);
-    }
-    blocks = blocks_for(4, B3);
-    if (pc.aabb_mode == RT_AABB_RCP)
-      hipLaunchKernelGGL((k_render_v2<RT_AABB_RCP, 4, B3, NL3, NC3, 0>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands, sched);
-    else
-      hipLaunchKernelGGL((k_render_v2<RT_AABB_DIV, 4, B3, NL3, NC3, 0>), dim3(blocks), dim3(B3), lds3, stream,
-                         sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue, regen_idle, nbands, sched);
-  }
+  const size_t lds_bytes = RT_LDS_STACK * RT_BLOCK * 4;
+  if (pc.aabb_mode == RT_AABB_RCP)
+    hipLaunchKernelGGL((k_render_v8<RT_AABB_RCP, RT_V8_MINW, RT_BLOCK, RT_LDS_STACK>), dim3(blocks), dim3(RT_BLOCK),
+                       lds_bytes, stream, sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue,
+                       regen_idle, sched);
+  else
+    hipLaunchKernelGGL((k_render_v8<RT_AABB_DIV, RT_V8_MINW, RT_BLOCK, RT_LDS_STACK>), dim3(blocks), dim3(RT_BLOCK),
+                       lds_bytes, stream, sc, cam, pc, reinterpret_cast<float4 *>(d_accum), d_counter, d_queue,
+                       regen_idle, sched);
 #ifdef RT_V2_STATS
-  if ((variant & 0xFFu) >= 2) {
+  {
     static const char *names[8] = {"shade", "fetch", "newpath", "arm", "pair", "inst", "leaf", "pop"};
     unsigned long long h[32], z[32] = {0};
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_v2_stats), sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_v2_stats), z, sizeof z);
-    fprintf(stderr, "[v2 stats] waves %llu wave_ticks %llu\n", h[25], h[24]);
+    fprintf(stderr, "[v8 stats] waves %llu wave_ticks %llu\n", h[25], h[24]);
     for (int i = 0; i < 8; ++i)
-      fprintf(stderr, "[v2 stats] %-8s ticks %14llu (%5.1f%%) exec %12llu lanes %14llu (%.1f/exec)\n", names[i],
+      fprintf(stderr, "[v8 stats] %-8s ticks %14llu (%5.1f%%) exec %12llu lanes %14llu (%.1f/exec)\n", names[i],
               h[i], 100.0 * (double)h[i] / (double)(h[24] ? h[24] : 1), h[8 + i], h[16 + i],
               h[8 + i] ? (double)h[16 + i] / (double)h[8 + i] : 0.0);
   }

@@ -134,3 +134,52 @@ def gather_interleaved(image, group=None):
             rows = min(ROW_GROUP, height - g * ROW_GROUP)
             image[g * ROW_GROUP: g * ROW_GROUP + rows].copy_(parts[r][k * ROW_GROUP: k * ROW_GROUP + rows])
     return image
+
+
+class InterleavedGather:
+    """The all-gather of `gather_interleaved` with everything per-step precomputed and nothing in place, so that it
+    can run on a side stream while the next launch already renders: `pack` copies this rank's row groups out of the
+    accumulation image (one gather kernel, on the render stream), `exchange` all-gathers the packed groups of every
+    rank and scatters them into `full`, a complete image of its own (one collective + one scatter kernel, on the
+    communication stream).  Two packed buffers alternate, so step k+1's `pack` never overwrites what step k's
+    collective still reads.  Values are moved, never re-associated: `full` equals the one-GPU image bit for bit.
+    Works on CPU tensors with gloo (tests) and on GPU tensors with RCCL."""
+
+    def __init__(self, height, width, channels=4, dtype=torch.float32, device="cpu", group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.height = height
+        groups = (height + ROW_GROUP - 1) // ROW_GROUP
+        self.per_rank = (groups + self.world - 1) // self.world   # padded: every rank sends the same size
+        rows_per_rank = self.per_rank * ROW_GROUP
+        # row r*rows_per_rank + j of the gathered buffer = image row src[r][j]; padding rows point at row `height`
+        # of a one-row-taller staging view, i.e. they are dropped on the way back
+        idx = torch.full((self.world, rows_per_rank), height, dtype=torch.int64)
+        for r in range(self.world):
+            rows = interleaved_rows(r, self.world, height)
+            idx[r, : len(rows)] = torch.tensor(rows, dtype=torch.int64)
+        self.my_rows = idx[self.rank].clamp(max=height - 1).to(device)        # pack: padding re-reads the last row
+        self.all_rows = idx.reshape(-1).to(device)                            # unpack: padding lands in the spare row
+        shape = (rows_per_rank, width, channels)
+        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(2)]
+        self.recv = torch.zeros((self.world * rows_per_rank, width, channels), dtype=dtype, device=device)
+        self.full_padded = torch.zeros((height + 1, width, channels), dtype=dtype, device=device)
+        self.full = self.full_padded[:height]
+        self.step = 0
+
+    def pack(self, image):
+        """Copies this rank's row groups out of `image` (H, W, C); returns the slot for `exchange`."""
+        slot = self.step & 1
+        self.step += 1
+        torch.index_select(image, 0, self.my_rows, out=self.send[slot])
+        return slot
+
+    def exchange(self, slot):
+        """All-gathers slot `slot` of every rank into `self.full` (complete image on every rank)."""
+        if self.world == 1:
+            self.recv.copy_(self.send[slot])
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send[slot], group=self.group)
+        self.full_padded.index_copy_(0, self.all_rows, self.recv)
+        return self.full

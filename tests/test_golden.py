@@ -80,7 +80,7 @@ def test_hip_reproduces_golden_hits(ctx, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10])
+@pytest.mark.parametrize("variant", [0, 8])
 @pytest.mark.parametrize("name", IMAGES)
 def test_hip_reproduces_golden_images(ctx, name, variant):
     sc, cam, (w, h, frames, sqrt_spp, depth, rng), want = _image_case(name)

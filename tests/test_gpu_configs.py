@@ -1,0 +1,148 @@
+"""Every BASELINE.json config as a GPU test on the kernel that ships (RT_KERNEL_VARIANT_AUTO, which must resolve
+to kernel 8 for these launches), against the oracle:
+
+  C1  Scenes/CornellBox through assets/scenes/cornell.json, 256x144, 16 spp, depth 8 — whole image vs the oracle
+  C2  assets/scenes/teapot.json at its stated 1920x1080, 64 spp, depth 8 — 40 rows vs the oracle + properties
+  C3  dragon-class stand-in (870,402 triangles), 1920x1080, depth 8 — properties + 40 rows vs the oracle
+  C4  many instances: tests/test_gpu_parity.py::test_many_instances_c4_scale (2025 instances, whole image)
+  C5  the C3 scene at 3840x2160 with defocus blur and the keyed PCG RNG — properties, three interleaved shares
+      stitched (the multi-GPU partition), 40 rows vs the oracle
+
+Where the oracle is too slow for the whole image inside the suite, size-independent properties carry the rest:
+the same launch twice gives the same bits, the reference-structured kernel 0 and the default kernel agree on
+every pixel, interleaved shares compose to the whole launch, alpha is 1 and everything is finite."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import _ffi
+from raytracing_amd import _types as T
+from raytracing_amd import renderer as R
+from raytracing_amd import sharding
+from . import _oracle as O
+from . import _scenes as S
+
+pytestmark = pytest.mark.gpu
+
+SCENES = os.path.join(S.ASSETS, "scenes")
+
+
+def _last_kernel(r):
+    st = _ffi.Stats()
+    _ffi._check(_ffi.lib().rt_get_stats(C.c_void_p(r.hip_context_handle()), C.byref(st)))
+    return st.last_kernel
+
+
+def _launch(r, cam, variant, rows=None):
+    r.set_option(R.OPT_KERNEL_VARIANT, variant)
+    for k, v in (rows or {"row_begin": 0, "row_end": 0, "row_group_stride": 0}).items():
+        r.set_option({"row_begin": R.OPT_ROW_BEGIN, "row_end": R.OPT_ROW_END,
+                      "row_group_stride": R.OPT_ROW_GROUP_STRIDE}[k], v)
+    r.reset_accumulation()
+    r.render(cam)
+    return r.read_image()
+
+
+def _same(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _properties_and_oracle_rows(r, cam, w, h, sqrt_spp, depth, rng_mode, shards=3, oracle_stride=33):
+    """The shared body of the full-size tests.  Returns the whole image of the default kernel."""
+    a = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
+    assert _last_kernel(r) == 8                                   # the shipping kernel is what ran
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all() and (a[..., :3] >= 0).all()
+    assert _same(a, _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO))    # deterministic
+    b = _launch(r, cam, 0)
+    assert _last_kernel(r) == 0
+    assert _same(a, b)                                            # reference-structured kernel == default kernel
+    stitched = np.zeros_like(a)
+    for rank in range(shards):                                    # the multi-GPU partition, on one GPU
+        img = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO, sharding.row_interleave(rank, shards, h))
+        mine = sharding.interleaved_rows(rank, shards, h)
+        stitched[mine] = img[mine]
+    assert _same(a, stitched)
+    sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
+    want = np.zeros_like(a)
+    p = O.render_params(w, h, 0, sqrt_spp, depth, rng_mode=rng_mode, row_begin=0, row_end=h,
+                        row_group_stride=oracle_stride)
+    O.render(sa, camu, p, want, nthreads=16)
+    rows = sharding.interleaved_rows(0, oracle_stride, h)
+    assert len(rows) >= 40 and _same(a[rows], want[rows])         # >= 40 rows spread over the image, bit for bit
+    return a
+
+
+def test_c1_cornell_scene_file_whole_image():
+    """C1 at the size BASELINE.md states: CornellBox-Original.obj through the scene file, 256x144, 16 spp, depth 8,
+    the whole image against the oracle, both kernels."""
+    w, h, sqrt_spp, depth = 256, 144, 4, 8
+    r = R.Renderer(w, h, device=0)
+    cam, info = r.load_scene_file(os.path.join(SCENES, "cornell.json"))
+    assert info["triangles"] == 36
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, sqrt_spp * sqrt_spp)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
+    want = O.render(sa, camu, O.render_params(w, h, 0, sqrt_spp, depth), nthreads=16)
+    got = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
+    assert _last_kernel(r) == 8
+    assert _same(got, want)
+    assert _same(_launch(r, cam, 0), want)
+    # second progressive frame on top of the first (RayTracing.slang:176-179)
+    r.set_option(R.OPT_KERNEL_VARIANT, _ffi.KERNEL_VARIANT_AUTO)
+    r.reset_accumulation()
+    r.render(cam)
+    r.render(cam)
+    O.render(sa, camu, O.render_params(w, h, 1, sqrt_spp, depth), want, nthreads=16)
+    assert _same(r.read_image(), want)
+    r.shutdown()
+
+
+def test_c2_teapot_scene_file_full_size():
+    """C2 at its stated size: teapot.obj through assets/scenes/teapot.json, 1920x1080, 64 spp, depth 8."""
+    w, h, sqrt_spp, depth = 1920, 1080, 8, 8
+    r = R.Renderer(w, h, device=0)
+    cam, info = r.load_scene_file(os.path.join(SCENES, "teapot.json"))
+    assert info["screen_width"] == w and info["screen_height"] == h and info["triangles"] == 1024
+    assert info["samples_per_pixel"] == 64 and info["max_depth"] == depth
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, sqrt_spp * sqrt_spp)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    _properties_and_oracle_rows(r, cam, w, h, sqrt_spp, depth, T.RNG_WANG)
+    r.shutdown()
+
+
+def test_c3_dragon_full_size():
+    """C3 at its full size (870,402-triangle dragon stand-in, 1920x1080, depth 8; 4 spp per launch so that kernel 0
+    and the oracle rows stay within seconds — bench.py runs the same scene at 256 spp per launch and checks a whole
+    4-spp frame against the oracle on every default run)."""
+    import bench
+    w, h, sqrt_spp, depth = 1920, 1080, 2, 8
+    r = R.Renderer(w, h, device=0)
+    cam, n_tris = bench.build_dragon_scene(R, r)
+    assert n_tris == 870402
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, sqrt_spp * sqrt_spp)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    _properties_and_oracle_rows(r, cam, w, h, sqrt_spp, depth, T.RNG_WANG)
+    r.shutdown()
+
+
+def test_c5_dragon_4k_defocus_pcg_sharded():
+    """C5: the dragon scene at 3840x2160 with defocus blur (Random.slang:57-70 semantics) and the keyed PCG RNG,
+    4 spp per launch; interleaved shares of three ranks stitch to the one-GPU image bit for bit, and 40 rows match
+    the oracle."""
+    import bench
+    w, h, sqrt_spp, depth = 3840, 2160, 2, 8
+    r = R.Renderer(w, h, device=0)
+    cam, n_tris = bench.build_dragon_scene(R, r, defocus=True)
+    assert n_tris == 870402 and cam.c.defocus_angle > 0
+    camu = r.camera_uniforms(cam)
+    assert camu.defocus_disk_u[3] == 1.0   # the kernels' "defocus on" flag
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, sqrt_spp * sqrt_spp)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    a = _properties_and_oracle_rows(r, cam, w, h, sqrt_spp, depth, T.RNG_PCG, oracle_stride=54)
+    # the blur does something: the same launch with a pinhole camera differs
+    pin = R.Camera(tuple(cam.c.position), tuple(cam.c.look_at), tuple(cam.c.v_up), cam.c.fov)
+    assert not _same(a, _launch(r, pin, _ffi.KERNEL_VARIANT_AUTO))
+    r.shutdown()
