@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every CPU this process may use")
     args = ap.parse_args()
+    if os.environ.get("BENCH_DUMP_AFTER"):  # debugging aid: Python stacks of every thread if the run takes this long
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_AFTER"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

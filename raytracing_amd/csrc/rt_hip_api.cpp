@@ -572,11 +572,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     pc.row_end = pc.image_height;
   if (pc.row_begin >= pc.row_end)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty row range");
-  // interleaved launches (rt_types.h): the stride counts 8-row groups, so the range starts on a group boundary and
-  // a stride beyond the number of groups in the image is a caller's mistake (8 * stride must not wrap either)
-  if (pc.row_group_stride > 1u && ((pc.row_begin & 7u) != 0u || pc.row_group_stride > pc.image_height / 8u + 1u))
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: row_group_stride > 1 needs row_begin % 8 == 0 and a stride of at "
-                                         "most image_height / 8 + 1 groups");
+  // interleaved launches (rt_types.h): the stride counts 8-row groups from row_begin on; 8 * stride must not wrap
+  // (rt_virtual_rows divides by it), and no image has more than 2^16 groups of its own
+  if (pc.row_group_stride > (1u << 16))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: row_group_stride exceeds 65536 groups");
   HIP_TRY(hipSetDevice(ctx->device));
   // Kernel choice when the caller set none (tools/bench_lowspp.py): the vote-scheduled persistent kernel, except
   // for a tiny scene rendered with a few short paths per pixel — the reference's live configuration, built-in

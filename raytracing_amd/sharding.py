@@ -179,6 +179,11 @@ class InterleavedGather:
         """All-gathers slot `slot` of every rank into `self.full` (complete image on every rank)."""
         if self.world == 1:
             self.recv.copy_(self.send[slot])
+        elif self.recv.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal on a shared GPU (bench.py --rehearse): gloo is a CPU transport, stage through host memory
+            got = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+            dist.all_gather_into_tensor(got, self.send[slot].cpu(), group=self.group)
+            self.recv.copy_(got)
         else:
             dist.all_gather_into_tensor(self.recv, self.send[slot], group=self.group)
         self.full_padded.index_copy_(0, self.all_rows, self.recv)

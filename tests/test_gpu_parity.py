@@ -202,6 +202,28 @@ def test_bad_input_is_rejected_not_launched(ctx):
         ctx.trace_closest(S.random_rays(4, 1))  # failed upload leaves no scene
 
 
+def test_bad_launch_parameters_are_rejected(ctx):
+    """A row_group_stride whose 8-fold wraps to 0 (the host would divide by it) or beyond 2^16 groups,
+    an unknown kernel number and an empty row range are refused with RT_ERR_INVALID_ARGUMENT, nothing is launched."""
+    sc = S.cornell_builtin().build()
+    ctx.upload_scene(sc)
+    w, h = 64, 40
+    ctx.set_camera(S.cornell_camera(w, h))
+    ctx.resize(w, h)
+    ctx.reset_stats()
+    for stride in (1 << 29, 1 << 30, (1 << 16) + 1):
+        with pytest.raises(_ffi.RtError):
+            ctx.render(O.render_params(w, h, 0, 1, 3, row_begin=0, row_end=h, row_group_stride=stride))
+    with pytest.raises(_ffi.RtError):
+        ctx.render(O.render_params(w, h, 0, 1, 3, row_begin=9, row_end=9))
+    for v in (1, 2, 3, 4, 5, 6, 7, 9, 10, 200):  # round 1's other kernels are no longer in the library
+        with pytest.raises(_ffi.RtError):
+            ctx.set_kernel_variant(v)
+    assert ctx.stats().launches == 0
+    ctx.render(O.render_params(w, h, 0, 1, 3, row_begin=0, row_end=h, row_group_stride=1 << 16))  # the largest legal stride
+    assert ctx.stats().launches == 1
+
+
 @pytest.mark.gpu
 def test_fast_division_is_ieee_division(ctx):
     """slab_pair_fast's division (rt_device_inl.h: refined reciprocal + two residual
