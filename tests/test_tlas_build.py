@@ -124,6 +124,19 @@ def test_gpu_cluster_equals_host_builder(ctx, kind, n, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_side", [6, 20, 45])
+def test_gpu_cluster_equals_oracle_builder(ctx, n_side):
+    """The GPU clustering kernel against the ORACLE's TLAS::build restatement directly (orc_build_tlas), not through
+    the product's host builder: 37, 401 and 2026 instances of the mixed scene."""
+    o = S.mixed_scene(n_side=n_side, seed=9)
+    so = o.build()
+    n = len(o.instances)
+    got, cnt, _ms = ctx.build_tlas_cluster(so.tlas_nodes[1:1 + n])  # the oracle's leaves, TLAS.cpp:15-36
+    assert cnt == so.tlas_node_count == 2 * n - 1
+    _same_struct(got[:cnt], so.tlas_nodes[:cnt])
+
+
+@pytest.mark.gpu
 def test_gpu_cluster_rejects_bad_input(ctx):
     lv = _leaves(8, 0)
     with pytest.raises(_ffi.RtError):
