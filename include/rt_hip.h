@@ -132,6 +132,16 @@ int rt_debug_fast_div(rt_ctx *ctx, const float *n, const float *d, uint64_t coun
 int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
                           uint32_t *out_node_count, float *kernel_ms);
 
+/* No counterpart in the reference.  rt_build_tlas_cluster for callers that cannot allocate device memory — a render
+ * loop that rebuilds the TLAS every frame, code under HIP graph capture, harnesses that forbid hipMalloc: the same
+ * kernel and the same results, with the staged leaves, the output nodes and the node count held in a static device
+ * array of the library (384 KiB + 256 B per GPU, resident until the process ends) instead of per-call hipMalloc /
+ * hipFree, and no events (no kernel time is reported).  Calls nothing that allocates.  n > RT_TLAS_GPU_MAX_LEAVES is
+ * refused with RT_ERR_INVALID_ARGUMENT.  Every context on a GPU shares that GPU's array: calls that overlap on one
+ * GPU race (calls of one context are ordered by its stream and the entry point waits before it returns). */
+int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                                  uint32_t *out_node_count);
+
 const char *rt_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only machine; never fails) */
 int rt_device_count(void);

@@ -20,6 +20,7 @@ SYMBOLS = [
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
     "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
+    "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
 ]
@@ -82,6 +83,7 @@ def lib():
     L.rt_set_stream.argtypes = [vp, vp]
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -145,6 +147,14 @@ class HipContext:
         _check(lib().rt_build_tlas_cluster(self._h, T.ptr(leaves), leaves.size, T.ptr(out), C.byref(count),
                                            C.byref(ms)))
         return out, int(count.value), float(ms.value)
+
+    def build_tlas_cluster_noalloc(self, leaves):
+        """rt_build_tlas_cluster_noalloc (static device scratch, no allocation): (nodes[2n], node_count)."""
+        leaves = np.ascontiguousarray(leaves, T.tlas_node_dtype)
+        out = np.zeros(2 * max(leaves.size, 1), T.tlas_node_dtype)
+        count = C.c_uint32(0)
+        _check(lib().rt_build_tlas_cluster_noalloc(self._h, T.ptr(leaves), leaves.size, T.ptr(out), C.byref(count)))
+        return out, int(count.value)
 
     def set_camera(self, cam):
         _check(lib().rt_set_camera(self._h, C.byref(cam)))

@@ -337,6 +337,8 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
   ctx->cus = (uint32_t)(cus > 0 ? cus : 0);
   if (e == hipSuccess && ctx->cus == 0)
     e = hipErrorInvalidDevice;
+  if (e == hipSuccess) // this device's address of the static scratch array (rt_build_tlas_cluster_noalloc)
+    e = rt_tlas_scratch_init(device_id);
   if (e != hipSuccess) {
     ctx->counter.release();
     ctx->queue.release();
@@ -816,6 +818,30 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
     HIP_TRY(hipEventElapsedTime(kernel_ms, ev.a, ev.b));
   if (count == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster: instance boxes are not finite");
+  *out_node_count = count;
+  return RT_OK;
+}
+
+int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                                  uint32_t *out_node_count) {
+  if (!ctx || !leaves || !out_nodes || !out_node_count || n == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: bad argument");
+  if (n > RT_TLAS_GPU_MAX_LEAVES)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: " + std::to_string(n) + " leaves exceed the " +
+                                             std::to_string(RT_TLAS_GPU_MAX_LEAVES) + " (RT_TLAS_GPU_MAX_LEAVES) the static "
+                                             "scratch buffer holds");
+  for (uint32_t k = 0; k < n; ++k) {
+    if (leaves[k].left_right != 0)
+      return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: input node is not a leaf");
+    for (int c = 0; c < 3; ++c) // the kernel's scan relies on finite boxes (rt_tlas_build.hip)
+      if (!std::isfinite(leaves[k].aabb_min[c]) || !std::isfinite(leaves[k].aabb_max[c]))
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: instance boxes are not finite");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t count = 0;
+  HIP_TRY(rt_run_tlas_cluster_noalloc(ctx->device, leaves, n, out_nodes, &count, ctx->stream));
+  if (count == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: instance boxes are not finite");
   *out_node_count = count;
   return RT_OK;
 }

@@ -56,6 +56,11 @@ hipError_t rt_launch_probe_walk(const rt_dev_scene &sc, uint32_t blocks, uint32_
 hipError_t rt_launch_tlas_cluster(const rt_tlas_node *d_leaves, uint32_t n, rt_tlas_node *d_out,
                                   uint32_t *d_out_count, hipStream_t stream);
 
+// the no-allocation variant: per-device scratch in a file-scope __device__ array of rt_tlas_build.hip
+hipError_t rt_tlas_scratch_init(int device); // once per device, with that device current (rt_create)
+hipError_t rt_run_tlas_cluster_noalloc(int device, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                                       uint32_t *out_count, hipStream_t stream);
+
 hipError_t rt_launch_debug_fast_div(const float *d_n, const float *d_d, uint64_t count, float *d_fast,
                                     float *d_ieee, hipStream_t stream);
 

@@ -229,3 +229,71 @@ hipError_t rt_launch_tlas_cluster(const rt_tlas_node *leaves, uint32_t n, rt_tla
   hipLaunchKernelGGL(k_tlas_cluster, dim3(1), dim3(TB_THREADS), lds, stream, leaves, n, cap, out, out_count);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// rt_build_tlas_cluster_noalloc: the same kernel for callers that cannot allocate.  Its device buffers (the staged
+// leaves, the 2n output nodes, the node count) live in this file-scope array instead of hipMalloc'd memory:
+// RT_TLAS_GPU_MAX_LEAVES leaves in, twice as many nodes out, one counter = 384 KiB + 256 B, held by every GPU the
+// library runs on until the process ends.  The array's name is only a host-side handle: each device has its own copy
+// at its own address, looked up once per device with hipGetSymbolAddress (rt_tlas_scratch_init, called by rt_create
+// with that device current) and used through that pointer everywhere below.  Every call on a GPU shares that GPU's
+// array, so calls that overlap on one GPU (two contexts, two threads) race; one context's calls are ordered by its stream.
+// ---------------------------------------------------------------------------
+#define TB_SCRATCH_LEAVES_BYTES ((size_t)RT_TLAS_GPU_MAX_LEAVES * sizeof(rt_tlas_node))
+#define TB_SCRATCH_OUT_BYTES (2 * (size_t)RT_TLAS_GPU_MAX_LEAVES * sizeof(rt_tlas_node))
+#define TB_SCRATCH_BYTES (TB_SCRATCH_LEAVES_BYTES + TB_SCRATCH_OUT_BYTES + 256)
+static __device__ __align__(256) unsigned char scratch[TB_SCRATCH_BYTES];
+static unsigned char *g_scratch_ptr[64]; // per device: the address of that device's copy of `scratch`
+
+hipError_t rt_tlas_scratch_init(int device) { // `device` is current
+  if (device < 0 || device >= 64)
+    return hipSuccess; // the no-allocation entry point refuses such a device; everything else works
+  if (g_scratch_ptr[device])
+    return hipSuccess;
+  void *p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess)
+    return e;
+  if (!p)
+    return hipErrorInvalidSymbol;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tlas_cluster), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)rt_tlas_cluster_lds_bytes(RT_TLAS_GPU_MAX_LEAVES));
+  if (e != hipSuccess)
+    return e;
+  g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+  return hipSuccess;
+}
+
+// Stages `leaves` (host) into the device's scratch, runs the clustering kernel there, copies 2n nodes and the count
+// back and waits.  No hipMalloc / hipFree / event creation.  n <= RT_TLAS_GPU_MAX_LEAVES is the caller's check.
+hipError_t rt_run_tlas_cluster_noalloc(int device, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
+                                       uint32_t *out_count, hipStream_t stream) {
+  if (device < 0 || device >= 64 || !g_scratch_ptr[device])
+    return hipErrorNotInitialized;
+  if (n == 0 || n > RT_TLAS_GPU_MAX_LEAVES)
+    return hipErrorInvalidValue;
+  unsigned char *base = g_scratch_ptr[device];
+  rt_tlas_node *d_leaves = reinterpret_cast<rt_tlas_node *>(base);
+  rt_tlas_node *d_out = reinterpret_cast<rt_tlas_node *>(base + TB_SCRATCH_LEAVES_BYTES);
+  uint32_t *d_count = reinterpret_cast<uint32_t *>(base + TB_SCRATCH_LEAVES_BYTES + TB_SCRATCH_OUT_BYTES);
+  // the array keeps the previous call's contents: the count must start at zero (a kernel that did not run then
+  // reads as a failure), and the output range of THIS call is cleared so that nothing of a larger, earlier call
+  // can be mistaken for a node of this one
+  hipError_t e = hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_out, 0, 2 * (size_t)n * sizeof(rt_tlas_node), stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_leaves, leaves, (size_t)n * sizeof(rt_tlas_node), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess)
+    return e;
+  const uint32_t cap = (n + 255u) & ~255u;
+  hipLaunchKernelGGL(k_tlas_cluster, dim3(1), dim3(TB_THREADS), rt_tlas_cluster_lds_bytes(cap), stream, d_leaves, n, cap,
+                     d_out, d_count);
+  e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(out_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(out_nodes, d_out, 2 * (size_t)n * sizeof(rt_tlas_node), hipMemcpyDeviceToHost, stream);
+  const hipError_t es = hipStreamSynchronize(stream); // also on an error path: nothing stays queued on the caller's arrays
+  return e != hipSuccess ? e : es;
+}
