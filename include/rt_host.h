@@ -39,7 +39,8 @@ enum rth_option {
   RTH_ROW_BEGIN = 7, /* multi-GPU row sharding: render rows [begin, end) only; 0,0 = all */
   RTH_ROW_END = 8,
   RTH_TLAS_GPU_MIN_INSTANCES = 9, /* TLAS clustering on the GPU from this many instances on; 0 = host only */
-  RTH_ROW_GROUP_STRIDE = 10 /* rt_render_params.row_group_stride: N = every N-th 8-row group from RTH_ROW_BEGIN on */
+  RTH_ROW_GROUP_STRIDE = 10, /* rt_render_params.row_group_stride: N = every N-th 8-row group from RTH_ROW_BEGIN on */
+  RTH_RENDER_FLAGS = 11      /* rt_render_params.flags (RT_RENDER_*) */
 };
 
 /* Renderer::init / shutdown / resize / render, src/Renderer.cpp:215-652.

@@ -190,8 +190,16 @@ typedef struct rt_render_params {
   uint32_t row_end;
   uint32_t row_group_stride; /* 0 or 1: every row of the range; N: only the 8-row groups row_begin/8 + k*N
                                 (multi-GPU interleaving: rank r sets row_begin = 8 r, stride = N) */
-  uint32_t reserved;
+  uint32_t flags; /* RT_RENDER_*; 0 = the documented reading of the reference */
 } rt_render_params;
+
+/* rt_render_params.flags.  The reference cannot be run here, so where its source admits two readings both are
+ * selectable (and tested against the oracle both ways).
+ * RT_RENDER_DIELECTRIC_ALWAYS_DRAWS: Material.slang:91 `cannot_refract || reflectance(..) > rand(seed)` — default
+ * (flag clear): `||` short-circuits as Slang / HLSL-2021 specify for scalars, so a ray that cannot refract draws no
+ * random number; flag set: both operands are evaluated (as a compiler that flattens the condition would), so every
+ * dielectric hit advances the RNG once. */
+#define RT_RENDER_DIELECTRIC_ALWAYS_DRAWS 1u
 
 /* RNG selection (RayTracing.slang:71-72 is RT_RNG_WANG). */
 enum rt_rng_mode {

@@ -1079,8 +1079,16 @@ void shade_pixel(const rt_scene_desc *sc, const rt_camera_uniforms *cam,
             float sin_theta = sqrtf(fmax_(0.f, 1.f - cos_theta * cos_theta));
             bool cannot_refract = ri * sin_theta > 1.f;
             V3 direction;
-            // `||` short-circuits: no draw when the ray cannot refract
-            if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
+            // `||` short-circuits: no draw when the ray cannot refract — unless the caller selects the other
+            // reading of Material.slang:91 (RT_RENDER_DIELECTRIC_ALWAYS_DRAWS: both operands evaluated)
+            bool reflects;
+            if (pc->flags & RT_RENDER_DIELECTRIC_ALWAYS_DRAWS) {
+              const float xi = rng.next();
+              reflects = cannot_refract || reflectance(cos_theta, ri) > xi;
+            } else {
+              reflects = cannot_refract || reflectance(cos_theta, ri) > rng.next();
+            }
+            if (reflects)
               direction = reflect(unit_direction, rec.normal);
             else
               direction = rtiow_refract(unit_direction, rec.normal, ri);

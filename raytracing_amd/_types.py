@@ -74,12 +74,13 @@ class RenderParams(C.Structure):  # src/Renderer.cpp:48-62
     _fields_ = [("image_width", u32), ("image_height", u32), ("frame_index", u32),
                 ("accum_count", u32), ("sqrt_spp", u32), ("max_depth", u32),
                 ("rng_mode", u32), ("aabb_mode", u32), ("row_begin", u32),
-                ("row_end", u32), ("row_group_stride", u32), ("reserved", u32)]
+                ("row_end", u32), ("row_group_stride", u32), ("flags", u32)]
 
 
 MATERIAL_LAMBERT, MATERIAL_METAL, MATERIAL_DIELECTRIC, MATERIAL_EMISSIVE, MATERIAL_NONE = 0, 1, 2, 3, 4
 RNG_WANG, RNG_PCG = 0, 1
 AABB_DIV, AABB_RCP = 0, 1
+RENDER_DIELECTRIC_ALWAYS_DRAWS = 1  # rt_render_params.flags
 INVALID_ID = 0xFFFFFFFF
 
 # numpy views of the same layouts (arrays of these are passed by pointer)

@@ -109,6 +109,9 @@ int rth_set_option(rth_renderer *r, int option, uint32_t value) {
   case RTH_ROW_GROUP_STRIDE:
     r->r.row_group_stride = value;
     break;
+  case RTH_RENDER_FLAGS:
+    r->r.render_flags = value;
+    break;
   case RTH_TLAS_GPU_MIN_INSTANCES:
     r->r.tlas_gpu_min_instances = value;
     return RT_OK; // the nodes are the same either way: the running mean stays valid

@@ -221,8 +221,14 @@ struct Asset {
       return true;
     }
     const View &v = views[(size_t)a.view];
+    // byteStride: glTF 2.0 allows 4..252 in steps of 4 and no less than the element; anything else is refused
+    // here, before it is multiplied (a crafted 2^40 stride times 2^24 elements wraps size_t)
+    if (v.stride && (v.stride < 4 || v.stride > 252 || (v.stride & 3u) || v.stride < elem))
+      return fail("bufferView byteStride must be a multiple of 4 in 4..252 and at least the element size");
     stride = v.stride ? v.stride : elem;
-    if (a.count && (a.offset > v.length || (a.count - 1) * stride + elem > v.length - a.offset))
+    // the last element must end inside the view; written without a multiplication that could overflow
+    if (a.count && (a.offset > v.length || elem > v.length - a.offset ||
+                    a.count - 1 > (v.length - a.offset - elem) / stride))
       return fail("accessor exceeds its bufferView");
     base = buffers[v.buffer].data() + v.offset + a.offset;
     return true;

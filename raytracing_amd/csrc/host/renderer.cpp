@@ -541,6 +541,7 @@ int Renderer::render(Camera &camera) {
   pc.max_depth = max_depth;
   pc.rng_mode = rng_mode, pc.aabb_mode = aabb_mode;
   pc.row_begin = row_begin, pc.row_end = row_end, pc.row_group_stride = row_group_stride;
+  pc.flags = render_flags;
   if ((rc = rt_render(ctx_, &pc)) != RT_OK) {
     last_error_ = rt_last_error_string();
     return rc;

@@ -113,6 +113,7 @@ public:
   uint32_t row_begin = 0, row_end = 0;
   // > 1: only every row_group_stride-th 8-row group of that range (multi-GPU row interleaving)
   uint32_t row_group_stride = 0;
+  uint32_t render_flags = 0; // rt_render_params.flags
   // TLAS rebuilds (Renderer.cpp:994-1015) with at least this many instances run their clustering loop on the GPU
   // (rt_build_tlas_cluster, up to RT_TLAS_GPU_MAX_LEAVES); 0 = always on the host.  Same nodes either way.
   uint32_t tlas_gpu_min_instances = 1536; // measured break-even against one host core (tools/bench_tlas.py)

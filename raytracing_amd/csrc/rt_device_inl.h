@@ -503,7 +503,7 @@ __device__ __forceinline__ void camera_ray(const rt_camera_uniforms &cam, float 
 
 // Everything after intersect_tlas in one bounce: RayTracing.slang:103-167.
 // Returns true when the path continues (scattered).
-__device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything, const Hit &hit,
+__device__ __forceinline__ bool shade(const rt_dev_scene &sc, uint32_t flags, bool hit_anything, const Hit &hit,
                                       Rng &rng, Path &p) {
   if (!hit_anything) { // :159-167
     V3 unit = normalize(p.d);
@@ -563,7 +563,14 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, bool hit_anything,
     float cos_theta = fmin_(dot(neg(unit), normal), 1.f);
     float sin_theta = sqrtf(fmax_(0.f, 1.f - cos_theta * cos_theta));
     bool cannot_refract = ri * sin_theta > 1.f;
-    if (cannot_refract || reflectance(cos_theta, ri) > rng.next())
+    bool reflects; // Material.slang:91, both readings (rt_types.h, RT_RENDER_DIELECTRIC_ALWAYS_DRAWS)
+    if (flags & RT_RENDER_DIELECTRIC_ALWAYS_DRAWS) {
+      const float xi = rng.next();
+      reflects = cannot_refract || reflectance(cos_theta, ri) > xi;
+    } else {
+      reflects = cannot_refract || reflectance(cos_theta, ri) > rng.next();
+    }
+    if (reflects)
       out_d = reflect(unit, normal);
     else
       out_d = rtiow_refract(unit, normal, ri);

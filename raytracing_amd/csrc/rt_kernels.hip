@@ -86,7 +86,7 @@ extern "C" __global__ void __launch_bounds__(RT_BLOCK)
           Hit hit;
           bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
           ++traced;
-          if (!shade(sc, any, hit, rng, p))
+          if (!shade(sc, pc.flags, any, hit, rng, p))
             break;
         }
         radiance = radiance + p.sample_radiance;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     V2_CNT(0, state == ST_SHADE);
     if (state == ST_SHADE) {
       hit.t = closest; // == the accepted t whenever `any`; keeping it out of the traversal loop saves a register
-      const bool scattered = shade(sc, any, hit, rng, p);
+      const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
       ++depth;
       if (scattered && depth < pc.max_depth) {
         state = ST_NEWPATH + 100u; // marker: start the next bounce below
@@ -329,20 +329,22 @@ __global__ void __launch_bounds__(BLOCK, MINW)
                             ((uint64_t)(ref & 0x7FFFFFFFu) * stride + (base - (uint64_t)(uintptr_t)sc.pairs));
             const unsigned long long m1 = __ballot(do1), m13 = __ballot(act != 0u);
             unsigned long long saved;
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
+            asm volatile("; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
                          "s_mov_b64 exec, %[m13]\n\t"
                          "global_load_dwordx4 %[a], %[q], off\n\t"
                          "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
                          "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
                          "s_mov_b64 exec, %[m1]\n\t"
                          "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
-                         "s_mov_b64 exec, %[sv]"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         "; RT_V8_LOADS_END"
                          : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
                          : [q] "v"(q), [m13] "s"(m13), [m1] "s"(m1)
                          : "memory");
           }
           if (do3) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qx), "+v"(qy), "+v"(qz));
+            asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_TRI" : "+v"(qx), "+v"(qy), "+v"(qz));
             if (__float_as_uint(qy.w))
               do_pop = true; // last triangle of the leaf
             else
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
             hit.tri = accept ? __float_as_uint(qx.w) : hit.tri, hit.inst = accept ? cur_inst : hit.inst;
           }
           if (do1) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
+            asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
             const float4 px = make_float4(qx.x, qx.y, qx.z, qx.w), py = make_float4(qy.x, qy.y, qy.z, qy.w),
                          pz = make_float4(qz.x, qz.y, qz.z, qz.w), pr = make_float4(qr.x, qr.y, 0.f, 0.f);
             float dist1, dist2;

@@ -20,6 +20,7 @@ OPT_FRAME_STRIDE, OPT_FRAME_OFFSET, OPT_KERNEL_VARIANT = 4, 5, 6
 OPT_ROW_BEGIN, OPT_ROW_END = 7, 8
 OPT_TLAS_GPU_MIN_INSTANCES = 9
 OPT_ROW_GROUP_STRIDE = 10
+OPT_RENDER_FLAGS = 11
 PLANE, CUBE, SPHERE = 0, 1, 2
 
 HOST_SYMBOLS = [

@@ -96,12 +96,13 @@ def camera_uniforms(position, look_at, v_up, fov_deg, width, height):
 
 def render_params(width, height, frame_index=0, sqrt_spp=1, max_depth=3,
                   rng_mode=T.RNG_WANG, aabb_mode=T.AABB_DIV, accum_count=None,
-                  row_begin=0, row_end=0, row_group_stride=0):
+                  row_begin=0, row_end=0, row_group_stride=0, flags=0):
     p = T.RenderParams()
     p.image_width, p.image_height, p.frame_index = width, height, frame_index
     p.accum_count = frame_index if accum_count is None else accum_count
     p.sqrt_spp, p.max_depth, p.rng_mode, p.aabb_mode = sqrt_spp, max_depth, rng_mode, aabb_mode
     p.row_begin, p.row_end, p.row_group_stride = row_begin, row_end, row_group_stride
+    p.flags = flags
     return p
 
 

@@ -285,6 +285,12 @@ def test_bad_assets_are_reported(tmp_path):
         "sparse": lambda d: d["accessors"][0].update(sparse={"count": 1}),
         "mode": lambda d: d["meshes"][0]["primitives"][0].update(mode=1),
         "range": lambda d: d["accessors"][0].update(count=4000),
+        # byteStride 2^40 with 2^24 + 1 elements: (count - 1) * stride wraps size_t to 0 — must be refused, not read
+        "stride_wrap": lambda d: (d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=1 << 40),
+                                  d["accessors"][0].update(count=(1 << 24) + 1)),
+        "stride_odd": lambda d: d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=13),
+        "stride_small": lambda d: d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=4),
+        "stride_large": lambda d: d["bufferViews"][d["accessors"][0]["bufferView"]].update(byteStride=256),
         "index": lambda d: d["accessors"][d["meshes"][2]["primitives"][0]["indices"]].update(bufferView=0),
         "cycle": lambda d: d["nodes"][2].update(children=[0]),
         "nomesh": lambda d: d["nodes"][3].update(mesh=7),

@@ -377,3 +377,94 @@ def test_stack_deeper_than_the_lds_part(ctx, variant):
     got_img = ctx.read_accum(w, h)
     ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
     _same_image(got_img, img)
+
+
+@pytest.mark.parametrize("variant", [0, 8])
+@pytest.mark.parametrize("rng", [T.RNG_WANG, T.RNG_PCG])
+def test_dielectric_condition_both_readings(ctx, variant, rng):
+    """Material.slang:91 `cannot_refract || reflectance(..) > rand(seed)` admits two readings (does a ray that
+    cannot refract still draw a random number?) and the reference cannot be run to decide: both are selectable
+    (rt_render_params.flags, RT_RENDER_DIELECTRIC_ALWAYS_DRAWS), both equal the oracle, and they differ from each
+    other under the sequential Wang RNG, where a skipped draw shifts every later draw of the pixel."""
+    sc = S.mixed_scene().build()
+    ctx.upload_scene(sc)
+    ctx.set_kernel_variant(variant)
+    w, h = 100, 52
+    cam = S.mixed_camera(w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    imgs = []
+    try:
+        for flags in (0, T.RENDER_DIELECTRIC_ALWAYS_DRAWS):
+            ctx.clear_accum()
+            p = O.render_params(w, h, 0, 3, 8, rng_mode=rng, flags=flags)
+            ctx.render(p)
+            got = ctx.read_accum(w, h)
+            _same_image(got, O.render(sc, cam, p, nthreads=8))
+            imgs.append(got)
+        with pytest.raises(_ffi.RtError):
+            ctx.render(O.render_params(w, h, 0, 1, 3, flags=2))  # unknown flag bit
+    finally:
+        ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
+    differ = not np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    # keyed PCG: the dielectric's draw is the only one of its bounce and the next bounce has its own key, so an
+    # unused extra draw changes nothing — the two readings only matter for the reference's sequential RNG
+    assert differ == (rng == T.RNG_WANG)
+
+
+def test_caller_supplied_instance_order_flows_through(ctx):
+    """The reference lists its TLAS leaves in std::unordered_set iteration order (Renderer.cpp:999-1000), which is
+    implementation-defined; oracle and product default to ascending id.  A caller holding the reference's arrays
+    hands over ITS order: the TLAS built from a permuted instance list (another tree shape) goes through
+    rt_upload_scene unchanged — hits and image equal the oracle's on the same arrays, and t is the same as with the
+    ascending order for every ray (only ids of equal-t ties may move)."""
+    r = S.mixed_scene(n_side=5, seed=3)
+    n = len(r.instances)
+    perm = np.random.default_rng(99).permutation(n).astype(np.uint32)
+    sc_asc, sc_perm = r.build(), r.build(instance_ids=perm)
+    cnt = sc_asc.tlas_node_count
+    assert sc_perm.tlas_node_count == cnt
+    assert sc_perm.tlas_nodes[:cnt].tobytes() != sc_asc.tlas_nodes[:cnt].tobytes()
+    rays = S.random_rays(20000, seed=5, center=(0, 0.5, 0), radius=5.0)
+    ctx.upload_scene(sc_asc)
+    hits_asc = ctx.trace_closest(rays)
+    ctx.upload_scene(sc_perm)
+    hits_perm = ctx.trace_closest(rays)
+    _same_hits(hits_perm, O.trace_closest(sc_perm, rays))
+    assert np.array_equal(hits_perm["t"].view(np.uint32), hits_asc["t"].view(np.uint32))
+    moved = (hits_perm["tri_id"] != hits_asc["tri_id"]) | (hits_perm["inst_id"] != hits_asc["inst_id"])
+    assert moved.mean() < 0.01
+    w, h = 96, 54
+    cam = S.mixed_camera(w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    p = O.render_params(w, h, 0, 2, 6)
+    ctx.render(p)
+    _same_image(ctx.read_accum(w, h), O.render(sc_perm, cam, p, nthreads=8))
+
+
+def test_hits_against_brute_force_on_a_dragon_submesh(ctx):
+    """Closest hits of the GPU traversal against orc_trace_brute — every triangle of every instance tested in turn,
+    no BVH, no stack, no slab test: an oracle path that shares no traversal code with the kernels — on a coarse
+    version of the bench mesh (the C3 dragon stand-in at 120 x 32 segments) in two instances."""
+    from raytracing_amd import renderer as R
+    mesh = R.Mesh.dragon(120, 32, 1234)
+    r = O.OracleRenderer()
+    b = r.add_blas(*mesh.arrays())
+    plane = r.add_blas(*S.plane_mesh())
+    r.add_blas_instance(b, O.trs(), r.default_material)
+    r.add_blas_instance(b, O.trs((1.2, 0.1, -0.4), O.angle_axis(0.7, (0, 1, 0)), (0.6, 0.6, 0.6)), r.default_material)
+    r.add_blas_instance(plane, O.trs((0, -0.28, 0), (1, 0, 0, 0), (14, 1, 14)), r.default_material)
+    sc = r.build()
+    assert mesh.triangle_count > 7000
+    ctx.upload_scene(sc)
+    rays = S.random_rays(6000, seed=13, center=(0.3, 0.4, 0), radius=2.5)
+    want = O.trace_brute(sc, rays)
+    for mode in (T.AABB_DIV, T.AABB_RCP):
+        got = ctx.trace_closest(rays, mode)
+        assert (got["tri_id"] != T.INVALID_ID).sum() > 1000
+        assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
+        # ids may differ only where two triangles give the same t (shared edges: the brute force keeps the
+        # first such triangle in array order, the reference's traversal the last one it visits)
+        diff = (got["tri_id"] != want["tri_id"]) | (got["inst_id"] != want["inst_id"])
+        assert diff.mean() < 0.02

@@ -39,5 +39,12 @@ flips(open(G._author(out, glb=False, embed=True)[0], "rb").read(), "fuzz_{}.gltf
 flips(open(G._author(out, glb=True, embed=True)[0], "rb").read(), "fuzz_{}.glb", 40, 0, 256, first=12)
 flips(open(os.path.join(ROOT, "assets", "teapot.obj"), "rb").read()[:20000], "fuzz_{}.obj", 40, 32, 127, per=20)
 flips(open(os.path.join(ROOT, "assets", "scenes", "multi.json"), "rb").read(), "fuzz_{}.json", 40, 32, 127)
+# crafted strides / counts whose product wraps size_t (gltf_file.cpp accessor bounds check)
+_doc = json.load(open(G._author(out, glb=False, embed=True)[0]))
+for k, (stride, count) in enumerate([(1 << 40, (1 << 24) + 1), (1 << 62, 5), (252, 1 << 28), (0xFFFFFFFFFFFF, 1 << 20)]):
+    d = json.loads(json.dumps(_doc))
+    d["bufferViews"][d["accessors"][0]["bufferView"]]["byteStride"] = stride
+    d["accessors"][0]["count"] = count
+    (out / f"stride_{k}.gltf").write_text(json.dumps(d))
 (out / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -3\nf 1 2 9\nf 1/5/7 2/2/2 3/3/3\nf 0 0 0\nvt 1\nvn\nf 1 2\n")
 print(len(list(out.iterdir())), "files in", out)
