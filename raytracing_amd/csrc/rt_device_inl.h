@@ -164,8 +164,9 @@ __device__ __forceinline__ void unpack_pair(float4 qx, float4 qy, float4 qz, flo
 // div_fmas' scaling and div_fixup are the identity, and what is left is
 //   r1 = fma(fma(-d, rcp(d), 1), rcp(d), rcp(d))            (depends on d only)
 //   q0 = n*r1; e0 = fma(-d,q0,n); q1 = fma(e0,r1,q0); e1 = fma(-d,q1,n); q = fma(e1,r1,q1)
+// of which q1 is already the correctly rounded quotient (see div2_exact).
 // The ray's three r1 are computed once per ray space (prep_space), the twelve
-// quotients of a pair record then cost 5 packed-fp32 instructions per two.
+// quotients of a pair record then cost 3 packed-fp32 instructions per two.
 // Preconditions, checked per ray space (fast_axis_ok) and per scene
 // (RT_SCENE_BOXES_MODERATE); a lane that fails them takes slab<MODE>:
 //   2^-30 <= |d| <= 2^30; o == 0 or 2^-66 <= |o| <= 2^59; box coordinate 0 or in
@@ -190,13 +191,16 @@ __device__ __forceinline__ bool fast_axis_ok(float o, float d) {
 __device__ __forceinline__ bool fast_axis_ok_rcp(float o, float inv) {
   return fabsf(inv) <= 3.0e38f && fabsf(o) <= 0x1p59f;
 }
+// ONE correction round is enough (round 2): q = fma(fma(-d, q0, n), r1, q0) with q0 = n * r1 equals the IEEE quotient
+// for EVERY pair of fp32 mantissas — checked exhaustively on the GPU, all 2^23 x 2^23 pairs (7.04e13, 35 s;
+// experiments/r02_div/div_exhaustive.hip, profiles/r02_div_exhaustive/), together with the exact scaling of r1 over
+// the exponent range of the preconditions — so the compiler's second round (e1, q2) is dropped: 3 instead of 5
+// packed instructions per two quotients, 18 instead of 30 per pair record.
 __device__ __forceinline__ f2v div2_exact(f2v n, float d, float r) {
   const f2v nd = {-d, -d}, rr = {r, r};
   const f2v q0 = n * rr;
   const f2v e0 = __builtin_elementwise_fma(nd, q0, n);
-  const f2v q1 = __builtin_elementwise_fma(e0, rr, q0);
-  const f2v e1 = __builtin_elementwise_fma(nd, q1, n);
-  return __builtin_elementwise_fma(e1, rr, q1);
+  return __builtin_elementwise_fma(e0, rr, q0);
 }
 // Per ray space (world, or an instance's object space): the reciprocals the slab
 // test uses and whether slab_pair_fast may be used.  DIV: inv = refined
