@@ -100,13 +100,22 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);
 /* Low byte: 0 = reference-structured kernel (one lane per pixel, nested sample / bounce / traversal loops);
  * 8 = persistent wave64s with path regeneration, a resumable per-lane traversal, vote scheduling and joined
- * pair / leaf steps (the default).  Higher bits are schedule knobs of kernel 8 (rt_kernels.hip, rt_launch_render).
- * Both give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new context) lets rt_render
- * choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and depth 3 per launch (the
- * reference's live configuration).  rt_stats.last_kernel reports the choice.  The kernels that round 1 measured
- * and dropped (numbers 1-7, 10) are in experiments/r01_variants/, outside the library. */
+ * pair / leaf steps (the default); 9 = sample-parallel wavefront pipeline (rt_wavefront.hip: trace, shade and
+ * resolve kernels over millions of path slots in HBM), only for RT_RNG_PCG — with the reference's sequential Wang
+ * RNG a pixel's samples cannot run side by side, and rt_render refuses kernel 9 (RT_ERR_UNSUPPORTED); rt_render
+ * blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
+ * rt_launch_render).  All kernels give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new
+ * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
+ * depth 3 per launch (the reference's live configuration).  rt_stats.last_kernel reports the choice.  The kernels
+ * that round 1 measured and dropped (numbers 1-7, 10) are in experiments/r01_variants/, outside the library. */
 #define RT_KERNEL_VARIANT_AUTO 0xFFFFFFFFu
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
+
+/* Sizing of kernel 9's HBM state (no counterpart in the reference): `paths_in_flight` path slots of 84 B (default
+ * 2^23 = 8 Mi paths, 0.7 GB) and `result_bytes` for the per-path sample radiances of one sample chunk (16 B per
+ * path, default 10 GiB: a 1920x1080 launch of 256 spp in one chunk; larger launches run in chunks of whole samples).
+ * Takes effect at the next launch. */
+int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t result_bytes);
 
 /* Measurement aid (no counterpart in the reference): every lane of `blocks`
  * 256-thread workgroups walks the uploaded node records for `steps` dependent,

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
@@ -81,6 +81,7 @@ def lib():
     L.rt_reset_stats.argtypes = [vp]
     L.rt_set_kernel_variant.argtypes = [vp, u32]
     L.rt_set_stream.argtypes = [vp, vp]
+    L.rt_set_wavefront_budget.argtypes = [vp, u32, u64]
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
@@ -204,6 +205,9 @@ class HipContext:
     def set_stream(self, hip_stream):
         """hip_stream: a hipStream_t as an integer (torch.cuda.Stream().cuda_stream), or None for the context's own."""
         _check(lib().rt_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_wavefront_budget(self, paths_in_flight, result_bytes):
+        _check(lib().rt_set_wavefront_budget(self._h, paths_in_flight, result_bytes))
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))

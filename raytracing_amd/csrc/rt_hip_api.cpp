@@ -12,6 +12,7 @@
 #include "../../include/rt_hip.h"
 #include "rt_flatten.h"
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 namespace {
 
@@ -75,6 +76,13 @@ struct rt_ctx {
   DevBuf<unsigned long long> counter;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
   uint32_t cus = 0;       // compute units of the device
+  // kernel 9 (rt_wavefront.hip): path state, per-path results and the pinned read-back of the list lengths
+  DevBuf<uint8_t> wf_state, wf_sr;
+  rt_wf_buffers wf{};
+  uint64_t wf_tile_slots = 0;
+  uint32_t wf_slots = 1u << 23;          // paths in flight (rt_set_wavefront_budget)
+  uint64_t wf_sr_bytes = 10ull << 30;    // result buffer: 16 B per path of a sample chunk
+  uint32_t *wf_h_ctrl = nullptr;
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -374,6 +382,10 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->counter.release();
   ctx->queue.release();
   ctx->accum_own.release();
+  ctx->wf_state.release();
+  ctx->wf_sr.release();
+  if (ctx->wf_h_ctrl)
+    (void)hipHostFree(ctx->wf_h_ctrl);
   if (ctx->own_stream)
     (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -586,12 +598,49 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
   const uint32_t variant = !ctx->variant_auto ? ctx->variant
                            : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
+  const bool wavefront = (variant & 0xFFu) == 9u;
+  if (wavefront) {
+    if (pc.rng_mode != RT_RNG_PCG)
+      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
+                                      "state runs through a pixel's samples, so they cannot be traced side by side");
+    // HBM state of the pipeline, sized for this launch shape and kept for the next one
+    const uint32_t rows = rt_virtual_rows(pc);
+    const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
+    const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
+    uint64_t want_slots = tile_slots * spp < ctx->wf_slots ? tile_slots * spp : ctx->wf_slots;
+    if (want_slots < 256)
+      want_slots = 256;
+    if (!ctx->wf_h_ctrl)
+      HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!ctx->wf_state.ptr || ctx->wf.slots < want_slots || ctx->wf_tile_slots < tile_slots) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;
+      const uint32_t sl = (uint32_t)(want_slots > ctx->wf.slots ? want_slots : ctx->wf.slots);
+      HIP_TRY(ctx->wf_state.reserve(rt_wf_state_bytes(sl, ts)));
+      rt_wf_carve(ctx->wf_state.ptr, sl, ts, ctx->wf);
+      ctx->wf_tile_slots = ts;
+    }
+    uint64_t sr_paths = tile_slots * spp; // everything in one chunk if the budget allows
+    if (sr_paths * 16 > ctx->wf_sr_bytes)
+      sr_paths = (ctx->wf_sr_bytes / 16 / tile_slots) * tile_slots;
+    if (sr_paths < tile_slots)
+      sr_paths = tile_slots; // at least one sample per chunk
+    if (!ctx->wf_sr.ptr || ctx->wf.sr_paths < sr_paths) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx->wf_sr.reserve((size_t)sr_paths * 16));
+      ctx->wf.sr = reinterpret_cast<float4 *>(ctx->wf_sr.ptr);
+      ctx->wf.sr_paths = sr_paths;
+    }
+  }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  const hipError_t le = rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                                         ctx->queue.ptr, effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
+  const hipError_t le =
+      wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->wf,
+                                             ctx->wf_h_ctrl, variant, ctx->cus, ctx->stream)
+                : rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
+                                   effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
   if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent
     ctx->free_events.push_back(ev);
     return fail(RT_ERR_HIP, std::string("rt_render: launch failed: ") + hipGetErrorString(le));
@@ -822,6 +871,20 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
   return RT_OK;
 }
 
+int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t result_bytes) {
+  if (!ctx || paths_in_flight < 256 || paths_in_flight > (1u << 28) || result_bytes < (1ull << 20))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_wavefront_budget: 256 .. 2^28 paths, at least 1 MiB of results");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->wf_slots = paths_in_flight;
+  ctx->wf_sr_bytes = result_bytes;
+  ctx->wf_state.release(); // re-sized by the next launch of kernel 9
+  ctx->wf_sr.release();
+  ctx->wf = rt_wf_buffers{};
+  ctx->wf_tile_slots = 0;
+  return RT_OK;
+}
+
 int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
                                   uint32_t *out_node_count) {
   if (!ctx || !leaves || !out_nodes || !out_node_count || n == 0)
@@ -852,8 +915,8 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant) {
     return RT_OK;
   }
   const uint32_t kernel = variant & 0xFFu;
-  if (!ctx || (kernel != 0 && kernel != 8))
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: the library holds kernels 0 and 8");
+  if (!ctx || (kernel != 0 && kernel != 8 && kernel != 9))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_kernel_variant: the library holds kernels 0, 8 and 9");
   ctx->variant_auto = false;
   // bits 0-7 kernel, 8-15 regen_idle (0 = automatic); higher bits: schedule knobs of kernel 8 (rt_launch_render)
   ctx->variant = variant & 0xFFFF00FFu;

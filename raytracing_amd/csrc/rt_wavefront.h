@@ -1,0 +1,38 @@
+// rt_wavefront.h — buffers and launcher of the sample-parallel wavefront pipeline (rt_wavefront.hip, kernel 9).
+#ifndef RT_WAVEFRONT_H
+#define RT_WAVEFRONT_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_kernels.h"
+
+// Path state between rounds, structure-of-arrays over path slots (84 B per slot in HBM), the slot lists of the
+// current and the next round, and the per-path result buffer of one sample chunk.
+struct rt_wf_buffers {
+  float4 *ray_o;      // [slots] origin.xyz, path id within the chunk (bits)
+  float4 *ray_d;      // [slots] direction.xyz, depth (bits)
+  float4 *att;        // [slots] attenuation.xyz
+  float4 *rad;        // [slots] sample_radiance.xyz
+  float4 *hit;        // [slots] t, triangle id (bits; RT_INVALID_ID = miss), instance id (bits), u
+  float *hit_v;       // [slots] v
+  uint32_t *surv[2];  // [slots] slots whose path continues with another bounce (ping-pong)
+  uint32_t *fresh[2]; // [slots] slots that received a new camera ray (ping-pong)
+  uint32_t *ctrl;     // [16] counters, see rt_wavefront.hip
+  float4 *partial;    // [tile slots] radiance summed over the sample chunks done so far
+  float4 *sr;         // [sr_paths] sample radiance of every path of the current chunk, in path-id order
+  uint32_t slots;     // capacity: paths in flight
+  uint64_t sr_paths;  // capacity of sr
+};
+
+size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots);
+void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b);
+
+// One rt_render launch through the pipeline.  h_ctrl: pinned host memory, 16 uint32.  Blocks the host until the
+// image is complete (the host reads the list lengths back between rounds).  pc.rng_mode must be RT_RNG_PCG.
+hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
+                                      const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
+                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
+                                      hipStream_t stream);
+
+#endif

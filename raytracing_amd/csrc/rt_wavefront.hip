@@ -1,0 +1,533 @@
+// rt_wavefront.hip — kernel 9: the sample-parallel wavefront pipeline for the keyed PCG RNG.
+//
+// The reference's RNG (a Wang hash whose state runs through all samples and bounces of a pixel,
+// Random.slang:7-19, RayTracing.slang:71-72) allows one path per pixel in flight, which is why the default kernel is
+// a megakernel: ray generation, traversal, shading and accumulation in one set of registers (109 VGPRs, 4 waves per
+// SIMD).  With the keyed PCG RNG of north_star — every draw a hash of (pixel, sample, bounce, dimension) — the
+// samples of a pixel are independent, so the path can be split where its register needs differ:
+//
+//   k_wf_shade (init)  fills the path slots with camera rays                                 (RayTracing.slang:78-90)
+//   k_wf_trace         closest hit of every live path's current ray: traversal state only    (TLAS.slang, BVHNode.slang)
+//   k_wf_shade         shades the hits at full lane occupancy, one lane per path, writes the scattered ray back into
+//                      the slot or ends the path and starts the slot's next one              (RayTracing.slang:103-170)
+//   k_wf_resolve       sums every pixel's sample radiances IN SAMPLE ORDER and folds them into the running mean
+//                                                                                            (RayTracing.slang:170-179)
+//
+// Path state lives in HBM between the kernels (84 B per slot, millions of slots: the design leans on MI355X's HBM
+// capacity and bandwidth instead of registers).  A path is the pair (pixel, sample); path ids run tile-major —
+// id = (tile * chunk_samples + sample) * 64 + pixel_in_tile — so consecutive ids are the 64 pixels of one 8x8 tile:
+// the camera rays of a wave are coherent, and the resolve kernel reads its samples coalesced.  Ended paths are
+// replaced in place from a global id counter, so every round traces about `slots` rays until the chunk runs out.
+// Per pixel the arithmetic, the RNG keys and the order of the radiance sum are those of k_render_v0 in PCG mode, so
+// the image is the same bit for bit.
+#include "rt_device_inl.h"
+#include "rt_wavefront.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ctrl words
+enum : uint32_t { WF_NEXT_ID = 0, WF_HEAD = 1, WF_SURV0 = 2, WF_FRESH0 = 3, WF_SURV1 = 4, WF_FRESH1 = 5 };
+
+struct WfChunk {
+  uint32_t s0;         // first sample of the chunk
+  uint32_t cs;         // samples in the chunk
+  uint32_t tiles_x;    // 8x8 tiles per (virtual) row of tiles
+  uint32_t total;      // path ids of the chunk: tiles * cs * 64
+};
+
+__device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const WfChunk &ch, uint32_t id, uint32_t &x,
+                                            uint32_t &y, uint32_t &sample) {
+  const uint32_t in = id & 63u, ts = id >> 6; // ts = tile * cs + sample_in_chunk
+  const uint32_t tile = ts / ch.cs;
+  sample = ch.s0 + (ts - tile * ch.cs);
+  x = (tile % ch.tiles_x) * 8u + (in & 7u);
+  y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
+}
+
+// Starts new paths in the slots of the lanes with want == true: ids come from the chunk's counter (one
+// wave-aggregated atomic per round of the loop), ids that fall on tile padding outside the image are skipped.
+// Returns true for lanes that wrote a camera ray into their slot.
+__device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, const rt_render_params &pc,
+                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+  bool started = false;
+  while (true) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull)
+      break;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) {
+      // look before adding: once the chunk is exhausted the counter must stop growing (it would wrap and hand
+      // out ids a second time); the waves in flight at that moment overshoot by at most 64 each
+      base = __hip_atomic_load(b.ctrl + WF_NEXT_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (base < ch.total)
+        base = atomicAdd(b.ctrl + WF_NEXT_ID, (uint32_t)__popcll(mask));
+    }
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (base >= ch.total) // the chunk is exhausted for everybody
+      break;
+    if (want) {
+      const uint32_t id = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (id >= ch.total) {
+        want = false;
+      } else {
+        uint32_t x, y, sample;
+        wf_pixel_of(pc, ch, id, x, y, sample);
+        if (x < pc.image_width && y < pc.row_end) { // else tile padding: draw another id
+          Rng rng = make_rng(pc, x, y);
+          rng.sample = pc.frame_index * spp + sample;
+          rng.set_slot(0);
+          Path p;
+          camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
+          b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
+          b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
+          b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+          want = false;
+          started = true;
+        }
+      }
+    }
+  }
+  return started;
+}
+
+// appends the slots of the lanes with `yes` to a list: one atomic per wave, lanes in order
+__device__ __forceinline__ void wf_append(uint32_t *list, uint32_t *counter, bool yes, uint32_t slot) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long mask = __ballot(yes);
+  if (mask == 0ull)
+    return;
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader)
+    base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, (int)leader, 64);
+  if (yes)
+    list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+// ---------------------------------------------------------------------------
+// k_wf_shade: one lane per live path.  INIT: no hit to shade, every lane of [0, n_fresh) just starts a path in slot
+// = its index (the first fill of a chunk).
+// ---------------------------------------------------------------------------
+template <bool INIT>
+__global__ void __launch_bounds__(RT_BLOCK)
+    k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t cur,
+               uint32_t n_surv, uint32_t n_fresh) {
+  const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const uint32_t n = n_surv + n_fresh;
+  const bool live = i < n;
+  const uint32_t nxt = cur ^ 1u;
+  uint32_t slot = 0;
+  bool ended = false, goes_on = false;
+  if (INIT) {
+    slot = i;
+    ended = live;
+  } else if (live) {
+    slot = i < n_surv ? b.surv[cur][i] : b.fresh[cur][i - n_surv];
+    const float4 ro = b.ray_o[slot], rd = b.ray_d[slot], at = b.att[slot], ra = b.rad[slot], h = b.hit[slot];
+    const uint32_t id = __float_as_uint(ro.w);
+    uint32_t depth = __float_as_uint(rd.w);
+    uint32_t x, y, sample;
+    wf_pixel_of(pc, ch, id, x, y, sample);
+    Rng rng = make_rng(pc, x, y);
+    rng.sample = pc.frame_index * (pc.sqrt_spp * pc.sqrt_spp) + sample;
+    rng.set_slot(depth + 1u);
+    Path p;
+    p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
+    p.attenuation = v3(at.x, at.y, at.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
+    Hit hit;
+    hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
+    const bool any = hit.tri != RT_INVALID_ID;
+    hit.v = any ? b.hit_v[slot] : 0.f;
+    const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
+    ++depth;
+    if (scattered && depth < pc.max_depth) {
+      b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
+      b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth));
+      b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
+      b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+      goes_on = true;
+    } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
+      b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+      ended = true;
+    }
+  }
+  wf_append(b.surv[nxt], b.ctrl + (nxt ? WF_SURV1 : WF_SURV0), goes_on, slot);
+  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot);
+  wf_append(b.fresh[nxt], b.ctrl + (nxt ? WF_FRESH1 : WF_FRESH0), started, slot);
+}
+
+// ---------------------------------------------------------------------------
+// k_wf_trace: persistent wave64s; a lane traces one ray at a time and takes the next list entry when it is done.  The
+// step loop is k_render_v8's (vote scheduling, joined pair / leaf steps, exact fast slab division); what a lane carries
+// besides it is only its slot and the world-space ray.
+// ---------------------------------------------------------------------------
+enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
+
+template <int MODE, int MINW, int BLOCK, int NLDS>
+__global__ void __launch_bounds__(BLOCK, MINW)
+    k_wf_trace(rt_dev_scene sc, rt_wf_buffers b, uint32_t cur, uint32_t n_surv, uint32_t n_fresh,
+               unsigned long long *ray_counter, uint32_t regen_idle, uint32_t sched_arg) {
+  extern __shared__ __align__(16) uint32_t lds_raw[];
+  uint32_t *lds_stack = lds_raw; // [NLDS][BLOCK]
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = n_surv + n_fresh;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(ray_counter, (unsigned long long)n);
+
+  uint32_t state = WT_FETCH, slot = 0;
+  V3 wo = v3(0.f, 0.f, 0.f), wd = v3(0.f, 0.f, 0.f); // the ray in world space
+  uint32_t ref = RT_REF_NONE, cur_inst = 0;
+  V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
+  const bool scene_ok = (sc.flags & RT_SCENE_BOXES_MODERATE) != 0u && !(sched_arg & 0x8000u);
+  float closest = 0.f, hit_u = 0.f, hit_v = 0.f;
+  uint32_t hit_tri = 0, hit_inst = 0;
+  uint32_t anyv = 0, fastv = 0;
+
+  const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
+  const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
+  const uint32_t w_inst = ((sched_arg >> 8) & 0xFu) ? ((sched_arg >> 8) & 0xFu) : 3u;
+  const uint32_t join_code = (sched_arg >> 12) & 7u;
+  const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
+                          : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
+
+  while (true) {
+    // ---- (1) finished rays: the hit record goes to the slot ----
+    if (state == WT_FINISHED) {
+      b.hit[slot] = make_float4(closest, __uint_as_float(anyv ? hit_tri : RT_INVALID_ID), __uint_as_float(hit_inst), hit_u);
+      if (anyv)
+        b.hit_v[slot] = hit_v;
+      state = WT_FETCH;
+    }
+    // ---- (2) lanes without a ray: next entries of the round's lists ----
+    {
+      const bool need = state == WT_FETCH;
+      const unsigned long long mask = __ballot(need);
+      uint32_t base = 0;
+      if (mask != 0ull) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        if (lane == leader) { // look before adding, as in wf_regenerate: the head stops near n
+          base = __hip_atomic_load(b.ctrl + WF_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (base < n)
+            base = atomicAdd(b.ctrl + WF_HEAD, (uint32_t)__popcll(mask));
+        }
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+      }
+      if (need) {
+        const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (idx >= n) {
+          state = WT_EXIT;
+        } else {
+          slot = idx < n_surv ? b.surv[cur][idx] : b.fresh[cur][idx - n_surv];
+          const float4 ro = b.ray_o[slot], rd = b.ray_d[slot];
+          wo = v3(ro.x, ro.y, ro.z), wd = v3(rd.x, rd.y, rd.z);
+          ref = sc.root_ref;
+          bool f2;
+          co = wo, cd = wd, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+          fastv = f2 ? 1u : 0u;
+          closest = 1000.f; // RayTracing.slang:93-95
+          anyv = 0u;
+          cur_inst = 0;
+          st.sp = 0;
+          state = ref == RT_REF_NONE ? WT_FINISHED : WT_TRAVERSE;
+        }
+      }
+    }
+    if (__ballot(state != WT_EXIT) == 0ull)
+      break;
+    const uint32_t n_done = (uint32_t)__popcll(__ballot(state == WT_EXIT));
+    // ---- (3) traversal steps while enough lanes are traversing (k_render_v8's loop) ----
+    while (true) {
+      const uint32_t top2 = ref >> 30;
+      const uint32_t kind = (state == WT_TRAVERSE ? 3u : 0u) & (0xB5u >> (top2 * 2u));
+      const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
+      const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
+      const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
+      if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
+        break;
+      const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
+      bool do_pop = false;
+      uint32_t sel;
+      if (s1 >= s2 && s1 >= s3)
+        sel = n3 >= join_min ? 10u : 2u;
+      else if (s3 >= s2)
+        sel = n1 >= join_min ? 10u : 8u;
+      else
+        sel = 4u;
+      const uint32_t act = ((sel >> kind) & 1u) ? kind : 0u;
+      if (sel != 4u) {
+        const bool do1 = act == 1u, do3 = act == 3u;
+        f4v qx, qy, qz;
+        f2v qr;
+        {
+          // the shared, EXEC-narrowing load group of k_render_v8 (see there for why it is inline assembly)
+          const uint32_t stride = kind == 3u ? 48u : 64u;
+          const uint64_t base = kind == 3u ? (uint64_t)(uintptr_t)sc.tris : (uint64_t)(uintptr_t)sc.pairs;
+          const char *q = reinterpret_cast<const char *>(sc.pairs) +
+                          ((uint64_t)(ref & 0x7FFFFFFFu) * stride + (base - (uint64_t)(uintptr_t)sc.pairs));
+          const unsigned long long m1 = __ballot(do1), m13 = __ballot(act != 0u);
+          unsigned long long saved;
+          asm volatile("; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)\n\t"
+                       "s_mov_b64 %[sv], exec\n\t"
+                       "s_mov_b64 exec, %[m13]\n\t"
+                       "global_load_dwordx4 %[a], %[q], off\n\t"
+                       "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
+                       "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
+                       "s_mov_b64 exec, %[m1]\n\t"
+                       "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
+                       "s_mov_b64 exec, %[sv]\n\t"
+                       "; RT_V8_LOADS_END"
+                       : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
+                       : [q] "v"(q), [m13] "s"(m13), [m1] "s"(m1)
+                       : "memory");
+        }
+        if (do3) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42 (branch-free form, see k_render_v8)
+          asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_TRI" : "+v"(qx), "+v"(qy), "+v"(qz));
+          if (__float_as_uint(qy.w))
+            do_pop = true;
+          else
+            ref = ref + 1u;
+          V3 v0 = v3(qx.x, qx.y, qx.z), edge_1 = v3(qy.x, qy.y, qy.z), edge_2 = v3(qz.x, qz.y, qz.z);
+          V3 h = cross(cd, edge_2);
+          float a = dot(edge_1, h);
+          float f = 1.f / a;
+          V3 s = co - v0;
+          float u = f * dot(s, h);
+          V3 qq = cross(s, edge_1);
+          float v = f * dot(cd, qq);
+          float t = f * dot(edge_2, qq);
+          const bool accept = !(a > -kEpsilon && a < kEpsilon) & !(u < 0 || u > 1) & !(v < 0 || u + v > 1) &
+                              !(t < kEpsilon || !(0.0001f <= t && t <= closest));
+          closest = accept ? t : closest;
+          anyv = accept ? 1u : anyv;
+          hit_u = accept ? u : hit_u, hit_v = accept ? v : hit_v;
+          hit_tri = accept ? __float_as_uint(qx.w) : hit_tri, hit_inst = accept ? cur_inst : hit_inst;
+        }
+        if (do1) {
+          asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
+          const float4 px = make_float4(qx.x, qx.y, qx.z, qx.w), py = make_float4(qy.x, qy.y, qy.z, qy.w),
+                       pz = make_float4(qz.x, qz.y, qz.z, qz.w), pr = make_float4(qr.x, qr.y, 0.f, 0.f);
+          float dist1, dist2;
+          if (fastv) {
+            slab_pair_fast<MODE>(co, cd, cinv, px, py, pz, closest, dist1, dist2);
+          } else {
+            float4 lo0, hi0, lo1, hi1;
+            unpack_pair(px, py, pz, pr, lo0, hi0, lo1, hi1);
+            dist1 = slab<MODE>(co, cd, cinv, lo0, hi0, closest);
+            dist2 = slab<MODE>(co, cd, cinv, lo1, hi1, closest);
+          }
+          uint32_t c1 = __float_as_uint(qr.x), c2 = __float_as_uint(qr.y);
+          if (dist1 > dist2) {
+            float tf = dist1;
+            dist1 = dist2;
+            dist2 = tf;
+            uint32_t tc = c1;
+            c1 = c2;
+            c2 = tc;
+          }
+          const bool hit1 = dist1 != kMiss, hit2 = dist2 != kMiss;
+          do_pop = !hit1;
+          ref = hit1 ? c1 : ref;
+          if (__ballot(hit2 && st.sp >= NLDS) != 0ull) {
+            if (hit2)
+              st.push(c2);
+          } else if (hit2) {
+            st.lds[st.sp * BLOCK] = c2;
+            ++st.sp;
+          }
+        }
+      } else {
+        if (act == 2u) {
+          cur_inst = ref & 0x3FFFFFFFu;
+          const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+          float4 a = q[0], bb = q[1], c = q[2], e = q[3];
+          V3 c0 = v3(a.x, a.y, a.z), c1 = v3(bb.x, bb.y, bb.z), c2 = v3(c.x, c.y, c.z), c3 = v3(e.x, e.y, e.z);
+          co = mul_cols(c0, c1, c2, c3, wo, 1.f), cd = mul_cols(c0, c1, c2, c3, wd, 0.f);
+          bool f2;
+          prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+          fastv = f2 ? 1u : 0u;
+          st.push(RT_REF_SENTINEL);
+          ref = __float_as_uint(a.w);
+        }
+      }
+      if (do_pop) {
+        if (st.sp == 0) {
+          state = WT_FINISHED;
+        } else {
+          ref = st.pop();
+          if (ref == RT_REF_SENTINEL) { // back to world space
+            bool f2;
+            co = wo, cd = wd, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+            fastv = f2 ? 1u : 0u;
+            if (st.sp == 0)
+              state = WT_FINISHED;
+            else
+              ref = st.pop();
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_wf_resolve: one lane per pixel; radiance = sum of the chunk's sample radiances in sample order on top of the
+// chunks before (RayTracing.slang:170), the last chunk folds it into the running mean (:174-179).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK)
+    k_wf_resolve(rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t tile_slots, float4 *__restrict__ accum,
+                 uint32_t first, uint32_t last) {
+  const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; // tile * 64 + pixel in tile
+  if (i >= tile_slots)
+    return;
+  const uint32_t tile = i >> 6, in = i & 63u;
+  const uint32_t x = (tile % ch.tiles_x) * 8u + (in & 7u);
+  const uint32_t y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
+  if (!(x < pc.image_width && y < pc.row_end))
+    return;
+  V3 radiance = v3(0.f, 0.f, 0.f);
+  if (!first) {
+    const float4 part = b.partial[i];
+    radiance = v3(part.x, part.y, part.z);
+  }
+  const float4 *sr = b.sr + ((size_t)tile * ch.cs) * 64u + in;
+  for (uint32_t s = 0; s < ch.cs; ++s) {
+    const float4 v = sr[(size_t)s * 64u];
+    radiance = radiance + v3(v.x, v.y, v.z);
+  }
+  if (last)
+    accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
+  else
+    b.partial[i] = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots) {
+  return (size_t)slots * (5 * sizeof(float4) + sizeof(float) + 4 * sizeof(uint32_t)) + 16 * sizeof(uint32_t) +
+         (size_t)tile_slots * sizeof(float4) + 16 * 256;
+}
+
+void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b) {
+  char *p = static_cast<char *>(state_mem);
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += (bytes + 255) & ~(size_t)255;
+    return r;
+  };
+  b.ctrl = reinterpret_cast<uint32_t *>(take(16 * sizeof(uint32_t)));
+  b.ray_o = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
+  b.ray_d = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
+  b.att = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
+  b.rad = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
+  b.hit = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
+  b.hit_v = reinterpret_cast<float *>(take((size_t)slots * sizeof(float)));
+  for (int k = 0; k < 2; ++k) {
+    b.surv[k] = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
+    b.fresh[k] = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
+  }
+  b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
+  b.slots = slots;
+}
+
+#ifndef RT_WF_MINW
+#define RT_WF_MINW 6 // resident waves per SIMD the trace kernel is built for
+#endif
+#define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per workgroup
+
+hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
+                                      const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
+                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
+                                      hipStream_t stream) {
+  const uint32_t rows = rt_virtual_rows(pc);
+  if (rows == 0 || pc.image_width == 0)
+    return hipSuccess;
+  if (cus == 0 || b.slots == 0 || pc.rng_mode != RT_RNG_PCG)
+    return hipErrorInvalidValue;
+  const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
+  const uint64_t tile_slots = (uint64_t)tiles_x * ((rows + 7u) >> 3) * 64u;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  uint64_t chunk = b.sr_paths / tile_slots; // samples whose results fit the result buffer
+  if (chunk > spp)
+    chunk = spp;
+  if (chunk != 0 && tile_slots * chunk > 0xF0000000ull) // path ids are 32-bit, with room for the counter's overshoot
+    chunk = 0xF0000000ull / tile_slots;
+  if (chunk == 0)
+    return hipErrorInvalidValue;
+  float4 *accum = reinterpret_cast<float4 *>(d_accum);
+  // knobs: bits 8-15 regeneration threshold of the trace kernel, 16-27 vote weights, 28-30 join code, 31 no fast slab
+  const uint32_t regen_idle = ((knobs >> 8) & 0xFFu) ? ((knobs >> 8) & 0xFFu) : 16u;
+  const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
+  const size_t lds_bytes = (size_t)RT_WF_NLDS * RT_BLOCK * 4;
+  const uint64_t resident = (uint64_t)cus * (RT_WF_MINW * 4u / (RT_BLOCK / 64u));
+  hipError_t e;
+  for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)chunk) {
+    WfChunk ch;
+    ch.s0 = s0;
+    ch.cs = (uint32_t)(spp - s0 < chunk ? spp - s0 : chunk);
+    ch.tiles_x = tiles_x;
+    ch.total = (uint32_t)(tile_slots * ch.cs);
+    const bool first = s0 == 0, last = s0 + ch.cs == spp;
+    if (pc.max_depth == 0) { // no bounce is traced: every sample contributes nothing (RayTracing.slang:92)
+      if ((e = hipMemsetAsync(b.sr, 0, (size_t)ch.total * sizeof(float4), stream)) != hipSuccess)
+        return e;
+    } else {
+      if ((e = hipMemsetAsync(b.ctrl, 0, 16 * sizeof(uint32_t), stream)) != hipSuccess)
+        return e;
+      uint32_t cur = 0;
+      const uint32_t fill = ch.total < b.slots ? ch.total : b.slots;
+      // first fill: lanes [0, fill) start paths in slots [0, fill); they land in fresh[1], so cur = 1 afterwards
+      hipLaunchKernelGGL((k_wf_shade<true>), dim3((fill + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, sc, cam,
+                         pc, b, ch, cur, 0u, fill);
+      cur = 1;
+      while (true) {
+        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+          return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+          return e;
+        const uint32_t n_surv = h_ctrl[cur ? WF_SURV1 : WF_SURV0], n_fresh = h_ctrl[cur ? WF_FRESH1 : WF_FRESH0];
+        const uint32_t n = n_surv + n_fresh;
+        if (n == 0)
+          break;
+        if (n > b.slots)
+          return hipErrorAssert; // cannot happen: every list entry is a distinct slot
+        // reset the queue head and the next round's counters (the current counters are host-side now)
+        const uint32_t nxt = cur ^ 1u;
+        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, sizeof(uint32_t), stream)) != hipSuccess)
+          return e;
+        if ((e = hipMemsetAsync(b.ctrl + (nxt ? WF_SURV1 : WF_SURV0), 0, 2 * sizeof(uint32_t), stream)) != hipSuccess)
+          return e;
+        const uint64_t need = ((uint64_t)n + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t blocks = (uint32_t)(need < resident ? need : resident);
+        if (pc.aabb_mode == RT_AABB_RCP)
+          hipLaunchKernelGGL((k_wf_trace<RT_AABB_RCP, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
+                             lds_bytes, stream, sc, b, cur, n_surv, n_fresh, d_counter, regen_idle, sched);
+        else
+          hipLaunchKernelGGL((k_wf_trace<RT_AABB_DIV, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
+                             lds_bytes, stream, sc, b, cur, n_surv, n_fresh, d_counter, regen_idle, sched);
+        hipLaunchKernelGGL((k_wf_shade<false>), dim3((uint32_t)need), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, cur,
+                           n_surv, n_fresh);
+        if ((e = hipGetLastError()) != hipSuccess)
+          return e;
+        cur = nxt;
+      }
+    }
+    hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,
+                       b, ch, (uint32_t)tile_slots, accum, first ? 1u : 0u, last ? 1u : 0u);
+    if ((e = hipGetLastError()) != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
+}

@@ -216,7 +216,7 @@ def test_bad_launch_parameters_are_rejected(ctx):
             ctx.render(O.render_params(w, h, 0, 1, 3, row_begin=0, row_end=h, row_group_stride=stride))
     with pytest.raises(_ffi.RtError):
         ctx.render(O.render_params(w, h, 0, 1, 3, row_begin=9, row_end=9))
-    for v in (1, 2, 3, 4, 5, 6, 7, 9, 10, 200):  # round 1's other kernels are no longer in the library
+    for v in (1, 2, 3, 4, 5, 6, 7, 10, 200):  # round 1's other kernels are no longer in the library
         with pytest.raises(_ffi.RtError):
             ctx.set_kernel_variant(v)
     assert ctx.stats().launches == 0
@@ -468,3 +468,104 @@ def test_hits_against_brute_force_on_a_dragon_submesh(ctx):
         # first such triangle in array order, the reference's traversal the last one it visits)
         diff = (got["tri_id"] != want["tri_id"]) | (got["inst_id"] != want["inst_id"])
         assert diff.mean() < 0.02
+
+
+# ---- kernel 9: the sample-parallel wavefront pipeline (rt_wavefront.hip), keyed PCG RNG only ----
+@pytest.mark.parametrize("knobs", [0, (4 << 8), (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24) | (5 << 28), 1 << 31])
+@pytest.mark.parametrize("name,sqrt_spp,depth", [("cornell", 1, 3), ("cornell", 3, 8), ("mixed", 2, 8), ("teapot", 4, 8)])
+def test_wavefront_image_bit_exact(ctx, name, sqrt_spp, depth, knobs):
+    make, camf = SCENES[name]
+    sc = make().build()
+    ctx.upload_scene(sc)
+    ctx.set_kernel_variant(9 | knobs)
+    w, h = 100, 52
+    cam = camf(w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    want = np.zeros((h, w, 4), np.float32)
+    try:
+        for frame in range(2):
+            p = O.render_params(w, h, frame, sqrt_spp, depth, rng_mode=T.RNG_PCG)
+            ctx.render(p)
+            O.render(sc, cam, p, want, nthreads=8)
+        got = ctx.read_accum(w, h)
+        assert ctx.stats().last_kernel == 9
+    finally:
+        ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
+    _same_image(got, want)
+
+
+@pytest.mark.parametrize("slots,result_bytes", [(256, 1 << 20), (1000, 3 << 20), (1 << 16, 1 << 20), (1 << 20, 1 << 30)])
+def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
+    """Few path slots (many rounds, every slot reused often) and a small result buffer (the launch runs in several
+    sample chunks whose partial sums continue each other) give the same bits; also rows, row interleaving, defocus,
+    RCP slabs, depth 0 and the rays counter."""
+    c = _ffi.HipContext(0)
+    try:
+        sc = S.mixed_scene().build()
+        c.upload_scene(sc)
+        c.set_kernel_variant(9)
+        c.set_wavefront_budget(slots, result_bytes)
+        from raytracing_amd import renderer as R
+        w, h = 136, 76
+        host = R.Renderer(w, h, device=None)
+        cam = host.camera_uniforms(R.Camera((3.5, 2.5, 4.5), (0, 0, 0), (0, 1, 0), 45.0, defocus_angle=1.0, focus_dist=6.0))
+        c.set_camera(cam)
+        c.resize(w, h)
+        c.reset_stats()
+        cn = O.Counters()
+        p = O.render_params(w, h, 0, 3, 6, rng_mode=T.RNG_PCG)
+        want = O.render(sc, cam, p, counters=cn, nthreads=8)
+        c.render(p)
+        _same_image(c.read_accum(w, h), want)
+        assert c.stats().rays_traced == cn.rays
+        # row bands and interleaved groups compose to the same frame; RCP slabs; a second frame on top
+        c.clear_accum()
+        for rows in ((0, 24, 2), (8, 24, 2), (24, h, 0)):
+            c.render(O.render_params(w, h, 0, 3, 6, rng_mode=T.RNG_PCG, row_begin=rows[0], row_end=rows[1], row_group_stride=rows[2]))
+        _same_image(c.read_accum(w, h), want)
+        p1 = O.render_params(w, h, 1, 2, 4, rng_mode=T.RNG_PCG, aabb_mode=T.AABB_RCP)
+        c.render(p1)
+        O.render(sc, cam, p1, want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
+        p2 = O.render_params(w, h, 2, 2, 0, rng_mode=T.RNG_PCG)  # depth 0: the frame contributes black
+        c.render(p2)
+        O.render(sc, cam, p2, want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
+        with pytest.raises(_ffi.RtError, match="PCG"):
+            c.render(O.render_params(w, h, 3, 1, 3, rng_mode=T.RNG_WANG))
+    finally:
+        c.close()
+
+
+def test_wavefront_deep_stack_and_edge_scenes(ctx):
+    """Kernel 9's trace kernel keeps 16 stack entries in LDS: the 38-instance chain drives it to 37; scenes outside the
+    fast slab preconditions take its literal slab test."""
+    ctx.set_kernel_variant(9)
+    try:
+        sc = _chain_scene().build()
+        ctx.upload_scene(sc)
+        w, h = 96, 40
+        cam = O.camera_uniforms((-1.0, 0.2, 0.1), (600.0, 0.0, 0.0), (0, 1, 0), 30.0, w, h)
+        ctx.set_camera(cam)
+        ctx.resize(w, h)
+        cn = O.Counters()
+        p = O.render_params(w, h, 0, 2, 6, rng_mode=T.RNG_PCG)
+        ctx.render(p)
+        want = O.render(sc, cam, p, counters=cn, nthreads=8)
+        assert cn.max_stack > 30
+        _same_image(ctx.read_accum(w, h), want)
+        for kind, cam_pos in (("tiny_vertex", (0, 0.75, 1.5)), ("stretched", (0, 1e25, 1.5)), ("squashed", (1e-30, 0.75, 1.5))):
+            sc = S.edge_scene(kind).build()
+            ctx.upload_scene(sc)
+            w, h = 72, 40
+            cam = O.camera_uniforms(cam_pos, (0, 0.75, -1), (0, 1, 0), 90.0, w, h)
+            ctx.set_camera(cam)
+            ctx.resize(w, h)
+            for mode in (T.AABB_DIV, T.AABB_RCP):
+                ctx.clear_accum()
+                p = O.render_params(w, h, 0, 2, 4, rng_mode=T.RNG_PCG, aabb_mode=mode)
+                ctx.render(p)
+                _same_image(ctx.read_accum(w, h), O.render(sc, cam, p, nthreads=8))
+    finally:
+        ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
