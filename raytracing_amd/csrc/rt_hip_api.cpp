@@ -611,7 +611,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     if (want_slots < 256)
       want_slots = 256;
     if (!ctx->wf_h_ctrl)
-      HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, 16 * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, RT_WF_CTRL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     if (!ctx->wf_state.ptr || ctx->wf.slots < want_slots || ctx->wf_tile_slots < tile_slots) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;

@@ -7,8 +7,9 @@
 
 #include "rt_kernels.h"
 
-// Path state between rounds, structure-of-arrays over path slots (84 B per slot in HBM), the slot lists of the
-// current and the next round, and the per-path result buffer of one sample chunk.
+// Path state between rounds, structure-of-arrays over path slots (84 B per slot in HBM; the depth word of ray_d is
+// 0xFFFFFFFF for a slot without a path), and the per-path result buffer of one sample chunk.
+#define RT_WF_CTRL_WORDS 256u
 struct rt_wf_buffers {
   float4 *ray_o;      // [slots] origin.xyz, path id within the chunk (bits)
   float4 *ray_d;      // [slots] direction.xyz, depth (bits)
@@ -16,9 +17,7 @@ struct rt_wf_buffers {
   float4 *rad;        // [slots] sample_radiance.xyz
   float4 *hit;        // [slots] t, triangle id (bits; RT_INVALID_ID = miss), instance id (bits), u
   float *hit_v;       // [slots] v
-  uint32_t *surv[2];  // [slots] slots whose path continues with another bounce (ping-pong)
-  uint32_t *fresh[2]; // [slots] slots that received a new camera ray (ping-pong)
-  uint32_t *ctrl;     // [16] counters, see rt_wavefront.hip
+  uint32_t *ctrl;     // [RT_WF_CTRL_WORDS] striped counters, see rt_wavefront.hip
   float4 *partial;    // [tile slots] radiance summed over the sample chunks done so far
   float4 *sr;         // [sr_paths] sample radiance of every path of the current chunk, in path-id order
   uint32_t slots;     // capacity: paths in flight
@@ -28,7 +27,7 @@ struct rt_wf_buffers {
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots);
 void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b);
 
-// One rt_render launch through the pipeline.  h_ctrl: pinned host memory, 16 uint32.  Blocks the host until the
+// One rt_render launch through the pipeline.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the
 // image is complete (the host reads the list lengths back between rounds).  pc.rng_mode must be RT_RNG_PCG.
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,

@@ -16,8 +16,10 @@
 // Path state lives in HBM between the kernels (84 B per slot, millions of slots: the design leans on MI355X's HBM
 // capacity and bandwidth instead of registers).  A path is the pair (pixel, sample); path ids run tile-major —
 // id = (tile * chunk_samples + sample) * 64 + pixel_in_tile — so consecutive ids are the 64 pixels of one 8x8 tile:
-// the camera rays of a wave are coherent, and the resolve kernel reads its samples coalesced.  Ended paths are
-// replaced in place from a global id counter, so every round traces about `slots` rays until the chunk runs out.
+// the camera rays a wave starts together are coherent, and the resolve kernel reads its samples coalesced.  A slot
+// belongs to one lane of the shade kernel for the whole chunk: when its path ends the lane starts the next path in
+// place (ids from striped counters), so there are no lists and no compaction, the state traffic of the shade kernel
+// is coalesced, and every round traces about `slots` rays until the chunk runs out.
 // Per pixel the arithmetic, the RNG keys and the order of the radiance sum are those of k_render_v0 in PCG mode, so
 // the image is the same bit for bit.
 #include "rt_device_inl.h"
@@ -27,14 +29,27 @@
 
 namespace {
 
-// ctrl words
-enum : uint32_t { WF_NEXT_ID = 0, WF_HEAD = 1, WF_SURV0 = 2, WF_FRESH0 = 3, WF_SURV1 = 4, WF_FRESH1 = 5 };
+// ctrl words.  Same-address atomics cost about 20 ns each device-wide (measured: a first version with one id counter,
+// one list counter and one queue head took 7 ms to hand 8 M paths to 131 K waves), so every hot counter is striped
+// over WF_STRIPES addresses and touched once per wave or per 512-slot chunk.
+#define WF_STRIPES 64u
+enum : uint32_t {
+  WF_ID = 0,                      // [WF_STRIPES] next path id of each band of the chunk's id space
+  WF_HEAD = WF_ID + WF_STRIPES,   // [WF_STRIPES] next slot of each band of the slot space (k_wf_trace)
+  WF_ALIVE = WF_HEAD + WF_STRIPES, // [WF_STRIPES] live paths after the round (summed by the host)
+  WF_IDS_DONE = WF_ALIVE + WF_STRIPES, // set once every id band is exhausted
+  WF_CTRL_WORDS = WF_IDS_DONE + 1
+};
+#define WF_DEAD 0xFFFFFFFFu // depth word of a slot without a path
 
 struct WfChunk {
-  uint32_t s0;         // first sample of the chunk
-  uint32_t cs;         // samples in the chunk
-  uint32_t tiles_x;    // 8x8 tiles per (virtual) row of tiles
-  uint32_t total;      // path ids of the chunk: tiles * cs * 64
+  uint32_t s0;       // first sample of the chunk
+  uint32_t cs;       // samples in the chunk
+  uint32_t tiles_x;  // 8x8 tiles per (virtual) row of tiles
+  uint32_t total;    // path ids of the chunk: tiles * cs * 64
+  uint32_t id_span;  // ids per band (a multiple of 64: a wave's ids stay within one tile and sample)
+  uint32_t slots;    // path slots in use for this chunk
+  uint32_t slot_span; // slots per band of the trace kernel's queue (a multiple of 64)
 };
 
 __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const WfChunk &ch, uint32_t id, uint32_t &x,
@@ -46,36 +61,46 @@ __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const Wf
   y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
 }
 
-// Starts new paths in the slots of the lanes with want == true: ids come from the chunk's counter (one
-// wave-aggregated atomic per round of the loop), ids that fall on tile padding outside the image are skipped.
-// Returns true for lanes that wrote a camera ray into their slot.
+// Starts new paths in the slots of the lanes with want == true.  Ids come from the band counters: the wave begins
+// at band `band`, takes ids for all its wanting lanes with one atomic, and moves on to the next band when one is
+// exhausted.  Ids on tile padding outside the image are skipped (the lane draws again).  Returns true for lanes that
+// wrote a camera ray into their slot; the others' slots are marked dead.
 __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, const rt_render_params &pc,
-                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot) {
+                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot,
+                                              uint32_t band) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
   bool started = false;
+  uint32_t tried = 0;
   while (true) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull)
       break;
+    if (tried >= WF_STRIPES || __hip_atomic_load(b.ctrl + WF_IDS_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      if (tried >= WF_STRIPES && lane == 0)
+        __hip_atomic_store(b.ctrl + WF_IDS_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    const uint32_t lo = band * ch.id_span;
+    const uint32_t hi = lo + ch.id_span < ch.total ? lo + ch.id_span : ch.total;
     const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) {
-      // look before adding: once the chunk is exhausted the counter must stop growing (it would wrap and hand
-      // out ids a second time); the waves in flight at that moment overshoot by at most 64 each
-      base = __hip_atomic_load(b.ctrl + WF_NEXT_ID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (base < ch.total)
-        base = atomicAdd(b.ctrl + WF_NEXT_ID, (uint32_t)__popcll(mask));
+    uint32_t base = 0xFFFFFFFFu;
+    if (lane == leader && lo < ch.total) {
+      // look before adding: an exhausted band's counter stops growing
+      base = __hip_atomic_load(b.ctrl + WF_ID + band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lo + base < hi)
+        base = atomicAdd(b.ctrl + WF_ID + band, (uint32_t)__popcll(mask));
     }
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    if (base >= ch.total) // the chunk is exhausted for everybody
-      break;
+    if (lo >= ch.total || base >= hi - lo) { // this band is exhausted for everybody: the next one
+      band = band + 1u == WF_STRIPES ? 0u : band + 1u;
+      ++tried;
+      continue;
+    }
     if (want) {
-      const uint32_t id = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (id >= ch.total) {
-        want = false;
-      } else {
+      const uint32_t id = lo + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (id < hi) { // else: the band ran out within this wave; retry (it is exhausted now)
         uint32_t x, y, sample;
         wf_pixel_of(pc, ch, id, x, y, sample);
         if (x < pc.image_width && y < pc.row_end) { // else tile padding: draw another id
@@ -97,94 +122,88 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
   return started;
 }
 
-// appends the slots of the lanes with `yes` to a list: one atomic per wave, lanes in order
-__device__ __forceinline__ void wf_append(uint32_t *list, uint32_t *counter, bool yes, uint32_t slot) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long mask = __ballot(yes);
-  if (mask == 0ull)
-    return;
-  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-  uint32_t base = 0;
-  if (lane == leader)
-    base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, (int)leader, 64);
-  if (yes)
-    list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
-}
-
 // ---------------------------------------------------------------------------
-// k_wf_shade: one lane per live path.  INIT: no hit to shade, every lane of [0, n_fresh) just starts a path in slot
-// = its index (the first fill of a chunk).
+// k_wf_shade: lane i owns path slot i for the whole chunk (no lists, no compaction: while the chunk has ids left
+// every slot is refilled the moment its path ends, so all slots stay busy; only the last rounds thin out).  All state
+// traffic is coalesced.  INIT: nothing to shade, every slot just starts a path (the first fill of a chunk).
 // ---------------------------------------------------------------------------
 template <bool INIT>
 __global__ void __launch_bounds__(RT_BLOCK)
-    k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t cur,
-               uint32_t n_surv, uint32_t n_fresh) {
-  const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-  const uint32_t n = n_surv + n_fresh;
-  const bool live = i < n;
-  const uint32_t nxt = cur ^ 1u;
-  uint32_t slot = 0;
+    k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch) {
+  const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const bool in_range = slot < ch.slots;
   bool ended = false, goes_on = false;
   if (INIT) {
-    slot = i;
-    ended = live;
-  } else if (live) {
-    slot = i < n_surv ? b.surv[cur][i] : b.fresh[cur][i - n_surv];
-    const float4 ro = b.ray_o[slot], rd = b.ray_d[slot], at = b.att[slot], ra = b.rad[slot], h = b.hit[slot];
-    const uint32_t id = __float_as_uint(ro.w);
+    ended = in_range;
+  } else if (in_range) {
+    const float4 rd = b.ray_d[slot];
     uint32_t depth = __float_as_uint(rd.w);
-    uint32_t x, y, sample;
-    wf_pixel_of(pc, ch, id, x, y, sample);
-    Rng rng = make_rng(pc, x, y);
-    rng.sample = pc.frame_index * (pc.sqrt_spp * pc.sqrt_spp) + sample;
-    rng.set_slot(depth + 1u);
-    Path p;
-    p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
-    p.attenuation = v3(at.x, at.y, at.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
-    Hit hit;
-    hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
-    const bool any = hit.tri != RT_INVALID_ID;
-    hit.v = any ? b.hit_v[slot] : 0.f;
-    const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
-    ++depth;
-    if (scattered && depth < pc.max_depth) {
-      b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
-      b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth));
-      b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
-      b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
-      goes_on = true;
-    } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
-      b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
-      ended = true;
+    if (depth != WF_DEAD) {
+      const float4 ro = b.ray_o[slot], at = b.att[slot], ra = b.rad[slot], h = b.hit[slot];
+      const uint32_t id = __float_as_uint(ro.w);
+      uint32_t x, y, sample;
+      wf_pixel_of(pc, ch, id, x, y, sample);
+      Rng rng = make_rng(pc, x, y);
+      rng.sample = pc.frame_index * (pc.sqrt_spp * pc.sqrt_spp) + sample;
+      rng.set_slot(depth + 1u);
+      Path p;
+      p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
+      p.attenuation = v3(at.x, at.y, at.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
+      Hit hit;
+      hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
+      const bool any = hit.tri != RT_INVALID_ID;
+      hit.v = any ? b.hit_v[slot] : 0.f;
+      const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
+      ++depth;
+      if (scattered && depth < pc.max_depth) {
+        b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
+        b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth));
+        b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
+        b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        goes_on = true;
+      } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
+        b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        ended = true;
+      }
     }
   }
-  wf_append(b.surv[nxt], b.ctrl + (nxt ? WF_SURV1 : WF_SURV0), goes_on, slot);
-  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot);
-  wf_append(b.fresh[nxt], b.ctrl + (nxt ? WF_FRESH1 : WF_FRESH0), started, slot);
+  const uint32_t wave = slot >> 6;
+  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot, wave % WF_STRIPES);
+  if (ended && !started)
+    b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
+  // live paths after this round, for the host's loop: one atomic per workgroup, striped
+  __shared__ uint32_t s_alive;
+  if (threadIdx.x == 0)
+    s_alive = 0;
+  __syncthreads();
+  const uint32_t n_wave = (uint32_t)__popcll(__ballot(goes_on || started));
+  if ((threadIdx.x & 63u) == 0 && n_wave)
+    atomicAdd(&s_alive, n_wave);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_alive)
+    atomicAdd(b.ctrl + WF_ALIVE + blockIdx.x % WF_STRIPES, s_alive);
 }
 
 // ---------------------------------------------------------------------------
-// k_wf_trace: persistent wave64s; a lane traces one ray at a time and takes the next list entry when it is done.  The
+// k_wf_trace: persistent wave64s; a lane traces one ray at a time and takes the next live slot when it is done.  The
 // step loop is k_render_v8's (vote scheduling, joined pair / leaf steps, exact fast slab division); what a lane carries
-// besides it is only its slot and the world-space ray.
+// besides it is only its slot and the world-space ray.  Slots are handed out in chunks of WF_GRAB consecutive slots
+// per atomic from striped queue heads.
 // ---------------------------------------------------------------------------
 enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
+#define WF_GRAB 512u
 
 template <int MODE, int MINW, int BLOCK, int NLDS>
 __global__ void __launch_bounds__(BLOCK, MINW)
-    k_wf_trace(rt_dev_scene sc, rt_wf_buffers b, uint32_t cur, uint32_t n_surv, uint32_t n_fresh,
-               unsigned long long *ray_counter, uint32_t regen_idle, uint32_t sched_arg) {
+    k_wf_trace(rt_dev_scene sc, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter, uint32_t regen_idle,
+               uint32_t sched_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw; // [NLDS][BLOCK]
   typedef float f4v __attribute__((ext_vector_type(4)));
   RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t n = n_surv + n_fresh;
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    atomicAdd(ray_counter, (unsigned long long)n);
 
-  uint32_t state = WT_FETCH, slot = 0;
+  uint32_t state = WT_FETCH, slot = 0, traced = 0;
   V3 wo = v3(0.f, 0.f, 0.f), wd = v3(0.f, 0.f, 0.f); // the ray in world space
   uint32_t ref = RT_REF_NONE, cur_inst = 0;
   V3 co = v3(0.f, 0.f, 0.f), cd = v3(0.f, 0.f, 0.f), cinv = v3(0.f, 0.f, 0.f);
@@ -192,6 +211,8 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   float closest = 0.f, hit_u = 0.f, hit_v = 0.f;
   uint32_t hit_tri = 0, hit_inst = 0;
   uint32_t anyv = 0, fastv = 0;
+  // the wave's share of the slot space (wave-uniform): [grab_next, grab_end), refilled from the band heads
+  uint32_t grab_next = 0, grab_end = 0, band = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES, bands_tried = 0;
 
   const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
   const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
@@ -208,39 +229,58 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         b.hit_v[slot] = hit_v;
       state = WT_FETCH;
     }
-    // ---- (2) lanes without a ray: next entries of the round's lists ----
-    {
+    // ---- (2) lanes without a ray: next live slots (wave-uniform loop; dead slots are skipped) ----
+    while (true) {
       const bool need = state == WT_FETCH;
       const unsigned long long mask = __ballot(need);
-      uint32_t base = 0;
-      if (mask != 0ull) {
-        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane == leader) { // look before adding, as in wf_regenerate: the head stops near n
-          base = __hip_atomic_load(b.ctrl + WF_HEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (base < n)
-            base = atomicAdd(b.ctrl + WF_HEAD, (uint32_t)__popcll(mask));
+      if (mask == 0ull)
+        break;
+      if (grab_next >= grab_end) { // the wave's share is used up: WF_GRAB more slots from a band head
+        if (bands_tried >= WF_STRIPES) {
+          if (need)
+            state = WT_EXIT;
+          break;
         }
-        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        const uint32_t lo = band * ch.slot_span;
+        const uint32_t hi = lo + ch.slot_span < ch.slots ? lo + ch.slot_span : ch.slots;
+        uint32_t base = 0xFFFFFFFFu;
+        if (lane == 0 && lo < ch.slots) {
+          base = __hip_atomic_load(b.ctrl + WF_HEAD + band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lo + base < hi)
+            base = atomicAdd(b.ctrl + WF_HEAD + band, WF_GRAB);
+        }
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (lo >= ch.slots || base >= hi - lo) {
+          band = band + 1u == WF_STRIPES ? 0u : band + 1u;
+          ++bands_tried;
+          continue;
+        }
+        grab_next = lo + base;
+        grab_end = grab_next + WF_GRAB < hi ? grab_next + WF_GRAB : hi;
       }
+      const uint32_t take = (uint32_t)__popcll(mask);
       if (need) {
-        const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx >= n) {
-          state = WT_EXIT;
-        } else {
-          slot = idx < n_surv ? b.surv[cur][idx] : b.fresh[cur][idx - n_surv];
-          const float4 ro = b.ray_o[slot], rd = b.ray_d[slot];
-          wo = v3(ro.x, ro.y, ro.z), wd = v3(rd.x, rd.y, rd.z);
-          ref = sc.root_ref;
-          bool f2;
-          co = wo, cd = wd, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
-          fastv = f2 ? 1u : 0u;
-          closest = 1000.f; // RayTracing.slang:93-95
-          anyv = 0u;
-          cur_inst = 0;
-          st.sp = 0;
-          state = ref == RT_REF_NONE ? WT_FINISHED : WT_TRAVERSE;
+        const uint32_t s = grab_next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (s < grab_end) {
+          const float4 rd = b.ray_d[s];
+          if (__float_as_uint(rd.w) != WF_DEAD) {
+            const float4 ro = b.ray_o[s];
+            slot = s;
+            wo = v3(ro.x, ro.y, ro.z), wd = v3(rd.x, rd.y, rd.z);
+            ref = sc.root_ref;
+            bool f2;
+            co = wo, cd = wd, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+            fastv = f2 ? 1u : 0u;
+            closest = 1000.f; // RayTracing.slang:93-95
+            anyv = 0u;
+            cur_inst = 0;
+            st.sp = 0;
+            ++traced;
+            state = ref == RT_REF_NONE ? WT_FINISHED : WT_TRAVERSE;
+          }
         }
       }
+      grab_next += take;
     }
     if (__ballot(state != WT_EXIT) == 0ull)
       break;
@@ -377,6 +417,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       }
     }
   }
+  count_rays(ray_counter, traced);
 }
 
 // ---------------------------------------------------------------------------
@@ -416,28 +457,25 @@ __global__ void __launch_bounds__(RT_BLOCK)
 // Host side
 // ---------------------------------------------------------------------------
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots) {
-  return (size_t)slots * (5 * sizeof(float4) + sizeof(float) + 4 * sizeof(uint32_t)) + 16 * sizeof(uint32_t) +
+  return (size_t)slots * (5 * sizeof(float4) + sizeof(float)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) +
          (size_t)tile_slots * sizeof(float4) + 16 * 256;
 }
 
 void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b) {
+  static_assert(WF_CTRL_WORDS <= RT_WF_CTRL_WORDS, "control block");
   char *p = static_cast<char *>(state_mem);
   auto take = [&](size_t bytes) {
     char *r = p;
     p += (bytes + 255) & ~(size_t)255;
     return r;
   };
-  b.ctrl = reinterpret_cast<uint32_t *>(take(16 * sizeof(uint32_t)));
+  b.ctrl = reinterpret_cast<uint32_t *>(take(RT_WF_CTRL_WORDS * sizeof(uint32_t)));
   b.ray_o = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.ray_d = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.att = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.rad = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.hit = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.hit_v = reinterpret_cast<float *>(take((size_t)slots * sizeof(float)));
-  for (int k = 0; k < 2; ++k) {
-    b.surv[k] = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
-    b.fresh[k] = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
-  }
   b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
   b.slots = slots;
 }
@@ -454,7 +492,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
   const uint32_t rows = rt_virtual_rows(pc);
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  if (cus == 0 || b.slots == 0 || pc.rng_mode != RT_RNG_PCG)
+  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG)
     return hipErrorInvalidValue;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint64_t tile_slots = (uint64_t)tiles_x * ((rows + 7u) >> 3) * 64u;
@@ -462,7 +500,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
   uint64_t chunk = b.sr_paths / tile_slots; // samples whose results fit the result buffer
   if (chunk > spp)
     chunk = spp;
-  if (chunk != 0 && tile_slots * chunk > 0xF0000000ull) // path ids are 32-bit, with room for the counter's overshoot
+  if (chunk != 0 && tile_slots * chunk > 0xF0000000ull) // path ids are 32-bit
     chunk = 0xF0000000ull / tile_slots;
   if (chunk == 0)
     return hipErrorInvalidValue;
@@ -472,6 +510,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
   const size_t lds_bytes = (size_t)RT_WF_NLDS * RT_BLOCK * 4;
   const uint64_t resident = (uint64_t)cus * (RT_WF_MINW * 4u / (RT_BLOCK / 64u));
+  auto span64 = [](uint64_t total) { // per-band share, a multiple of 64
+    const uint64_t per = (total + WF_STRIPES - 1) / WF_STRIPES;
+    return (uint32_t)((per + 63) / 64 * 64);
+  };
   hipError_t e;
   for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)chunk) {
     WfChunk ch;
@@ -479,49 +521,46 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
     ch.cs = (uint32_t)(spp - s0 < chunk ? spp - s0 : chunk);
     ch.tiles_x = tiles_x;
     ch.total = (uint32_t)(tile_slots * ch.cs);
+    ch.id_span = span64(ch.total);
+    ch.slots = ch.total < b.slots ? (ch.total + 63u) / 64u * 64u : b.slots / 64u * 64u;
+    if (ch.slots > b.slots)
+      ch.slots = b.slots / 64u * 64u;
+    ch.slot_span = span64(ch.slots);
     const bool first = s0 == 0, last = s0 + ch.cs == spp;
     if (pc.max_depth == 0) { // no bounce is traced: every sample contributes nothing (RayTracing.slang:92)
       if ((e = hipMemsetAsync(b.sr, 0, (size_t)ch.total * sizeof(float4), stream)) != hipSuccess)
         return e;
     } else {
-      if ((e = hipMemsetAsync(b.ctrl, 0, 16 * sizeof(uint32_t), stream)) != hipSuccess)
+      if ((e = hipMemsetAsync(b.ctrl, 0, RT_WF_CTRL_WORDS * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
-      uint32_t cur = 0;
-      const uint32_t fill = ch.total < b.slots ? ch.total : b.slots;
-      // first fill: lanes [0, fill) start paths in slots [0, fill); they land in fresh[1], so cur = 1 afterwards
-      hipLaunchKernelGGL((k_wf_shade<true>), dim3((fill + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, sc, cam,
-                         pc, b, ch, cur, 0u, fill);
-      cur = 1;
+      const uint32_t shade_blocks = (ch.slots + RT_BLOCK - 1) / RT_BLOCK;
+      // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
+      hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
       while (true) {
-        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+        // live paths after the last shade: the host decides whether another round is needed
+        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + WF_ALIVE, WF_STRIPES * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
           return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess)
           return e;
-        const uint32_t n_surv = h_ctrl[cur ? WF_SURV1 : WF_SURV0], n_fresh = h_ctrl[cur ? WF_FRESH1 : WF_FRESH0];
-        const uint32_t n = n_surv + n_fresh;
-        if (n == 0)
+        uint64_t alive = 0;
+        for (uint32_t k = 0; k < WF_STRIPES; ++k)
+          alive += h_ctrl[k];
+        if (alive == 0)
           break;
-        if (n > b.slots)
-          return hipErrorAssert; // cannot happen: every list entry is a distinct slot
-        // reset the queue head and the next round's counters (the current counters are host-side now)
-        const uint32_t nxt = cur ^ 1u;
-        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, sizeof(uint32_t), stream)) != hipSuccess)
+        // reset the trace kernel's queue heads and the live counters (contiguous in the control block)
+        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, 2 * WF_STRIPES * sizeof(uint32_t), stream)) != hipSuccess)
           return e;
-        if ((e = hipMemsetAsync(b.ctrl + (nxt ? WF_SURV1 : WF_SURV0), 0, 2 * sizeof(uint32_t), stream)) != hipSuccess)
-          return e;
-        const uint64_t need = ((uint64_t)n + RT_BLOCK - 1) / RT_BLOCK;
+        const uint64_t need = (alive + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t blocks = (uint32_t)(need < resident ? need : resident);
         if (pc.aabb_mode == RT_AABB_RCP)
           hipLaunchKernelGGL((k_wf_trace<RT_AABB_RCP, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
-                             lds_bytes, stream, sc, b, cur, n_surv, n_fresh, d_counter, regen_idle, sched);
+                             lds_bytes, stream, sc, b, ch, d_counter, regen_idle, sched);
         else
           hipLaunchKernelGGL((k_wf_trace<RT_AABB_DIV, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
-                             lds_bytes, stream, sc, b, cur, n_surv, n_fresh, d_counter, regen_idle, sched);
-        hipLaunchKernelGGL((k_wf_shade<false>), dim3((uint32_t)need), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, cur,
-                           n_surv, n_fresh);
+                             lds_bytes, stream, sc, b, ch, d_counter, regen_idle, sched);
+        hipLaunchKernelGGL((k_wf_shade<false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
         if ((e = hipGetLastError()) != hipSuccess)
           return e;
-        cur = nxt;
       }
     }
     hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,
