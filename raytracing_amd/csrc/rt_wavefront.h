@@ -9,7 +9,7 @@
 
 // Path state between rounds, structure-of-arrays over path slots (84 B per slot in HBM; the depth word of ray_d is
 // 0xFFFFFFFF for a slot without a path), and the per-path result buffer of one sample chunk.
-#define RT_WF_CTRL_WORDS 256u
+#define RT_WF_CTRL_WORDS 8192u
 struct rt_wf_buffers {
   float4 *ray_o;      // [slots] origin.xyz, path id within the chunk (bits)
   float4 *ray_d;      // [slots] direction.xyz, depth (bits)
@@ -18,6 +18,7 @@ struct rt_wf_buffers {
   float4 *hit;        // [slots] t, triangle id (bits; RT_INVALID_ID = miss), instance id (bits), u
   float *hit_v;       // [slots] v
   uint32_t *ctrl;     // [RT_WF_CTRL_WORDS] striped counters, see rt_wavefront.hip
+  uint32_t *block_pos; // [slots / 256] every shade workgroup's position in its share of the chunk's path ids
   float4 *partial;    // [tile slots] radiance summed over the sample chunks done so far
   float4 *sr;         // [sr_paths] sample radiance of every path of the current chunk, in path-id order
   uint32_t slots;     // capacity: paths in flight

@@ -32,13 +32,14 @@ namespace {
 // ctrl words.  Same-address atomics cost about 20 ns each device-wide (measured: a first version with one id counter,
 // one list counter and one queue head took 7 ms to hand 8 M paths to 131 K waves), so every hot counter is striped
 // over WF_STRIPES addresses and touched once per wave or per 512-slot chunk.
+// Atomics execute at the L2 per cache line, so the stripes of one counter sit WF_PAD words (256 B) apart: counters
+// packed into one line serialise like a single address.
 #define WF_STRIPES 64u
+#define WF_PAD 64u
 enum : uint32_t {
-  WF_ID = 0,                      // [WF_STRIPES] next path id of each band of the chunk's id space
-  WF_HEAD = WF_ID + WF_STRIPES,   // [WF_STRIPES] next slot of each band of the slot space (k_wf_trace)
-  WF_ALIVE = WF_HEAD + WF_STRIPES, // [WF_STRIPES] live paths after the round (summed by the host)
-  WF_IDS_DONE = WF_ALIVE + WF_STRIPES, // set once every id band is exhausted
-  WF_CTRL_WORDS = WF_IDS_DONE + 1
+  WF_HEAD = 0,                              // [WF_STRIPES * WF_PAD] next slot of each band of the slot space (k_wf_trace)
+  WF_ALIVE = WF_HEAD + WF_STRIPES * WF_PAD, // [..] live paths after the round (summed by the host)
+  WF_CTRL_WORDS = WF_ALIVE + WF_STRIPES * WF_PAD
 };
 #define WF_DEAD 0xFFFFFFFFu // depth word of a slot without a path
 
@@ -47,7 +48,6 @@ struct WfChunk {
   uint32_t cs;       // samples in the chunk
   uint32_t tiles_x;  // 8x8 tiles per (virtual) row of tiles
   uint32_t total;    // path ids of the chunk: tiles * cs * 64
-  uint32_t id_span;  // ids per band (a multiple of 64: a wave's ids stay within one tile and sample)
   uint32_t slots;    // path slots in use for this chunk
   uint32_t slot_span; // slots per band of the trace kernel's queue (a multiple of 64)
 };
@@ -61,46 +61,47 @@ __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const Wf
   y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
 }
 
-// Starts new paths in the slots of the lanes with want == true.  Ids come from the band counters: the wave begins
-// at band `band`, takes ids for all its wanting lanes with one atomic, and moves on to the next band when one is
-// exhausted.  Ids on tile padding outside the image are skipped (the lane draws again).  Returns true for lanes that
-// wrote a camera ray into their slot; the others' slots are marked dead.
+// Starts new paths in the slots of the lanes with want == true.  No global atomics (same-line atomics run at about
+// 50 M/s device-wide; a first version with id counters shared between waves spent more time on them than on
+// shading): every WORKGROUP owns a private, strided share of the chunk's id space — its j-th group of 64 ids is
+// group blockIdx + j * gridDim of the chunk, so a workgroup's paths are spread over the whole image (equal work)
+// while the ids one wave starts together are the pixels of one tile and sample (coherent camera rays).  The
+// workgroup's position in its share lives in b.block_pos[blockIdx], touched by one thread per round.  Ids on tile
+// padding outside the image are skipped (the lane draws again).  Returns true for lanes that wrote a camera ray.
+// Must be called by all threads of the workgroup.
 __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, const rt_render_params &pc,
-                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot,
-                                              uint32_t band) {
-  const uint32_t lane = threadIdx.x & 63u;
+                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot) {
+  __shared__ uint32_t s_cnt[RT_BLOCK / 64], s_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
   bool started = false;
-  uint32_t tried = 0;
   while (true) {
     const unsigned long long mask = __ballot(want);
-    if (mask == 0ull)
-      break;
-    if (tried >= WF_STRIPES || __hip_atomic_load(b.ctrl + WF_IDS_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-      if (tried >= WF_STRIPES && lane == 0)
-        __hip_atomic_store(b.ctrl + WF_IDS_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+    if (lane == 0)
+      s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) {
+      before += w < wave ? s_cnt[w] : 0u;
+      total += s_cnt[w];
     }
-    const uint32_t lo = band * ch.id_span;
-    const uint32_t hi = lo + ch.id_span < ch.total ? lo + ch.id_span : ch.total;
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0xFFFFFFFFu;
-    if (lane == leader && lo < ch.total) {
-      // look before adding: an exhausted band's counter stops growing
-      base = __hip_atomic_load(b.ctrl + WF_ID + band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lo + base < hi)
-        base = atomicAdd(b.ctrl + WF_ID + band, (uint32_t)__popcll(mask));
+    if (total == 0)
+      break; // uniform over the workgroup
+    if (threadIdx.x == 0) {
+      const uint32_t pos = b.block_pos[blockIdx.x];
+      b.block_pos[blockIdx.x] = pos + total;
+      s_base = pos;
     }
-    base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    if (lo >= ch.total || base >= hi - lo) { // this band is exhausted for everybody: the next one
-      band = band + 1u == WF_STRIPES ? 0u : band + 1u;
-      ++tried;
-      continue;
-    }
+    __syncthreads();
     if (want) {
-      const uint32_t id = lo + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (id < hi) { // else: the band ran out within this wave; retry (it is exhausted now)
+      const uint32_t p = s_base + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      const uint64_t id64 = ((uint64_t)blockIdx.x + (uint64_t)(p >> 6) * gridDim.x) * 64u + (p & 63u);
+      if (id64 >= ch.total) {
+        want = false; // the workgroup's share is used up (later positions lie even further out)
+      } else {
+        const uint32_t id = (uint32_t)id64;
         uint32_t x, y, sample;
         wf_pixel_of(pc, ch, id, x, y, sample);
         if (x < pc.image_width && y < pc.row_end) { // else tile padding: draw another id
@@ -118,6 +119,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
         }
       }
     }
+    __syncthreads(); // s_cnt / s_base are rewritten by the next turn
   }
   return started;
 }
@@ -167,8 +169,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
       }
     }
   }
-  const uint32_t wave = slot >> 6;
-  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot, wave % WF_STRIPES);
+  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot);
   if (ended && !started)
     b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
   // live paths after this round, for the host's loop: one atomic per workgroup, striped
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
     atomicAdd(&s_alive, n_wave);
   __syncthreads();
   if (threadIdx.x == 0 && s_alive)
-    atomicAdd(b.ctrl + WF_ALIVE + blockIdx.x % WF_STRIPES, s_alive);
+    atomicAdd(b.ctrl + WF_ALIVE + (blockIdx.x % WF_STRIPES) * WF_PAD, s_alive);
 }
 
 // ---------------------------------------------------------------------------
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   uint32_t hit_tri = 0, hit_inst = 0;
   uint32_t anyv = 0, fastv = 0;
   // the wave's share of the slot space (wave-uniform): [grab_next, grab_end), refilled from the band heads
-  uint32_t grab_next = 0, grab_end = 0, band = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES, bands_tried = 0;
+  uint32_t grab_next = 0, grab_end = 0, band = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
 
   const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
   const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
@@ -236,25 +237,26 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       if (mask == 0ull)
         break;
       if (grab_next >= grab_end) { // the wave's share is used up: WF_GRAB more slots from a band head
-        if (bands_tried >= WF_STRIPES) {
+        // lane l looks at band l: one parallel load tells which bands have slots left (see wf_regenerate)
+        const uint32_t my_lo = lane * ch.slot_span;
+        const uint32_t my_hi = my_lo + ch.slot_span < ch.slots ? my_lo + ch.slot_span : ch.slots;
+        const uint32_t my_cnt = __hip_atomic_load(b.ctrl + WF_HEAD + lane * WF_PAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long avail = __ballot(my_lo < ch.slots && my_cnt < my_hi - my_lo);
+        if (avail == 0ull) {
           if (need)
             state = WT_EXIT;
           break;
         }
+        const unsigned long long rot = band ? ((avail >> band) | (avail << (64u - band))) : avail;
+        band = (band + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
         const uint32_t lo = band * ch.slot_span;
         const uint32_t hi = lo + ch.slot_span < ch.slots ? lo + ch.slot_span : ch.slots;
-        uint32_t base = 0xFFFFFFFFu;
-        if (lane == 0 && lo < ch.slots) {
-          base = __hip_atomic_load(b.ctrl + WF_HEAD + band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (lo + base < hi)
-            base = atomicAdd(b.ctrl + WF_HEAD + band, WF_GRAB);
-        }
+        uint32_t base = 0;
+        if (lane == 0)
+          base = atomicAdd(b.ctrl + WF_HEAD + band * WF_PAD, WF_GRAB);
         base = (uint32_t)__shfl((int)base, 0, 64);
-        if (lo >= ch.slots || base >= hi - lo) {
-          band = band + 1u == WF_STRIPES ? 0u : band + 1u;
-          ++bands_tried;
+        if (base >= hi - lo) // taken in between: look again
           continue;
-        }
         grab_next = lo + base;
         grab_end = grab_next + WF_GRAB < hi ? grab_next + WF_GRAB : hi;
       }
@@ -458,6 +460,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
 // ---------------------------------------------------------------------------
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots) {
   return (size_t)slots * (5 * sizeof(float4) + sizeof(float)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) +
+         ((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t) +
          (size_t)tile_slots * sizeof(float4) + 16 * 256;
 }
 
@@ -477,6 +480,7 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buf
   b.hit = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.hit_v = reinterpret_cast<float *>(take((size_t)slots * sizeof(float)));
   b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
+  b.block_pos = reinterpret_cast<uint32_t *>(take(((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t)));
   b.slots = slots;
 }
 
@@ -521,7 +525,6 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
     ch.cs = (uint32_t)(spp - s0 < chunk ? spp - s0 : chunk);
     ch.tiles_x = tiles_x;
     ch.total = (uint32_t)(tile_slots * ch.cs);
-    ch.id_span = span64(ch.total);
     ch.slots = ch.total < b.slots ? (ch.total + 63u) / 64u * 64u : b.slots / 64u * 64u;
     if (ch.slots > b.slots)
       ch.slots = b.slots / 64u * 64u;
@@ -534,24 +537,28 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
       if ((e = hipMemsetAsync(b.ctrl, 0, RT_WF_CTRL_WORDS * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
       const uint32_t shade_blocks = (ch.slots + RT_BLOCK - 1) / RT_BLOCK;
+      if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
+        return e;
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
       hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
       while (true) {
         // live paths after the last shade: the host decides whether another round is needed
-        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + WF_ALIVE, WF_STRIPES * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + WF_ALIVE, WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
           return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess)
           return e;
         uint64_t alive = 0;
         for (uint32_t k = 0; k < WF_STRIPES; ++k)
-          alive += h_ctrl[k];
+          alive += h_ctrl[k * WF_PAD];
         if (alive == 0)
           break;
         // reset the trace kernel's queue heads and the live counters (contiguous in the control block)
-        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, 2 * WF_STRIPES * sizeof(uint32_t), stream)) != hipSuccess)
+        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t), stream)) != hipSuccess)
           return e;
-        const uint64_t need = (alive + RT_BLOCK - 1) / RT_BLOCK;
-        const uint32_t blocks = (uint32_t)(need < resident ? need : resident);
+        // the grid scans ALL slots for live ones (dead slots cost a 16-byte read), so it is sized by the slots: sized
+        // by the live paths, a round with a handful of stragglers ran in one workgroup and took 12 ms
+        const uint64_t need = ((uint64_t)ch.slots + WF_GRAB - 1) / WF_GRAB; // one wave per WF_GRAB slots at least
+        const uint32_t blocks = (uint32_t)(need / (RT_BLOCK / 64) + 1 < resident ? need / (RT_BLOCK / 64) + 1 : resident);
         if (pc.aabb_mode == RT_AABB_RCP)
           hipLaunchKernelGGL((k_wf_trace<RT_AABB_RCP, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
                              lds_bytes, stream, sc, b, ch, d_counter, regen_idle, sched);
