@@ -78,6 +78,9 @@ struct rt_ctx {
   uint32_t cus = 0;       // compute units of the device
   // kernel 9 (rt_wavefront.hip): path state, per-path results and the pinned read-back of the list lengths
   DevBuf<uint8_t> wf_state, wf_sr;
+  DevBuf<uint8_t> wf_geom;    // [pair records | triangles] in ONE allocation: 32-bit record offsets from one base
+  bool wf_geom_dirty = true;  // scene or instances changed since wf_geom was filled
+  rt_wf_geom wf_geom_desc{};
   rt_wf_buffers wf{};
   uint64_t wf_tile_slots = 0;
   uint32_t wf_slots = 1u << 23;          // paths in flight (rt_set_wavefront_budget)
@@ -302,6 +305,7 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.root_ref = root;
   ctx->dev.cache_pairs = cached;
   ctx->pair_count = (uint32_t)all.size();
+  ctx->wf_geom_dirty = true;
   ctx->dev.flags = moderate ? RT_SCENE_BOXES_MODERATE : 0u;
   return RT_OK;
 }
@@ -384,6 +388,7 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->accum_own.release();
   ctx->wf_state.release();
   ctx->wf_sr.release();
+  ctx->wf_geom.release();
   if (ctx->wf_h_ctrl)
     (void)hipHostFree(ctx->wf_h_ctrl);
   if (ctx->own_stream)
@@ -620,6 +625,24 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       rt_wf_carve(ctx->wf_state.ptr, sl, ts, ctx->wf);
       ctx->wf_tile_slots = ts;
     }
+    if (ctx->wf_geom_dirty || !ctx->wf_geom.ptr) {
+      // the trace kernel's cooperative fetch addresses pair records and triangles as 32-bit offsets from one base
+      const size_t pair_bytes = ((size_t)ctx->pair_count * sizeof(rt_dev_pair) + 255) & ~(size_t)255;
+      const size_t tri_bytes = ctx->tris.count * sizeof(rt_dev_tri);
+      if (pair_bytes + tri_bytes + 256 >= (1ull << 32))
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 addresses node records and triangles with 32-bit offsets "
+                                        "(scene too large)");
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx->wf_geom.reserve(pair_bytes + tri_bytes + 64));
+      if (ctx->pair_count)
+        HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr, ctx->pairs.ptr, (size_t)ctx->pair_count * sizeof(rt_dev_pair),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr + pair_bytes, ctx->tris.ptr, tri_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->wf_geom_desc.base = ctx->wf_geom.ptr;
+      ctx->wf_geom_desc.pairs_off = 0;
+      ctx->wf_geom_desc.tris_off = (uint32_t)pair_bytes;
+      ctx->wf_geom_dirty = false;
+    }
     uint64_t sr_paths = tile_slots * spp; // everything in one chunk if the budget allows
     if (sr_paths * 16 > ctx->wf_sr_bytes)
       sr_paths = (ctx->wf_sr_bytes / 16 / tile_slots) * tile_slots;
@@ -637,8 +660,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   if (rc != RT_OK)
     return rc;
   const hipError_t le =
-      wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->wf,
-                                             ctx->wf_h_ctrl, variant, ctx->cus, ctx->stream)
+      wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->wf_geom_desc, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
+                                             ctx->wf, ctx->wf_h_ctrl, variant, ctx->cus, ctx->stream)
                 : rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
                                    effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
   if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent

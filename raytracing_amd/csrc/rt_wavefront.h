@@ -25,12 +25,20 @@ struct rt_wf_buffers {
   uint64_t sr_paths;  // capacity of sr
 };
 
+// pair records and triangles in one allocation (copies of rt_dev_scene's arrays): the cooperative fetch of the trace
+// kernel forms addresses as base + 32-bit offset
+struct rt_wf_geom {
+  const uint8_t *base;
+  uint32_t pairs_off; // byte offset of pair record 0
+  uint32_t tris_off;  // byte offset of triangle 0
+};
+
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots);
 void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b);
 
 // One rt_render launch through the pipeline.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the
 // image is complete (the host reads the list lengths back between rounds).  pc.rng_mode must be RT_RNG_PCG.
-hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
+hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
                                       const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
                                       hipStream_t stream);

@@ -194,15 +194,36 @@ __global__ void __launch_bounds__(RT_BLOCK)
 enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
 #define WF_GRAB 512u
 
-template <int MODE, int MINW, int BLOCK, int NLDS>
+//
+// COOP: quad-cooperative record fetch.  A lane that gathers its own 64-byte record with four 16-byte loads costs the
+// CU's texture path one cache-line lookup per lane and instruction: 256 per wave step, which is where the per-lane
+// gather saturates (k_probe_walk: 139 G record visits/s chip-wide; this kernel ran at 115 G).  Here the four lanes of a
+// quad fetch ONE lane's record per instruction, 16 bytes each — one line lookup per quad, 64 per wave step (the probe
+// reaches 270-300 G visits/s this way) — and the four instructions serve the quad's four records.  The data cannot
+// stay in the fetching lanes' registers (a lane would hold pieces of four different records), so the loads are
+// LDS-DMA (global_load_lds_dwordx4: destination = M0 + 16 * lane): instruction j drops the complete record of quad
+// q's lane j at staging + j * WF_COOP_STRIDE + 64 * q, and every lane reads its own record back with ds_read_b128.
+// WF_COOP_STRIDE = 1040 = 1024 + 16 keeps the four lanes of a quad on different banks.  Instruction j runs only for
+// the quads whose lane j takes a step (EXEC from a DPP compare), addresses are 32-bit offsets from one base
+// (rt_wf_geom) so that a DPP add forms them in one instruction.
+#define WF_COOP_STRIDE 1040u
+#define WF_COOP_BYTES (4u * WF_COOP_STRIDE) // per wave
+
+template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP>
 __global__ void __launch_bounds__(BLOCK, MINW)
-    k_wf_trace(rt_dev_scene sc, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter, uint32_t regen_idle,
-               uint32_t sched_arg) {
+    k_wf_trace(rt_dev_scene sc, rt_wf_geom geom, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter,
+               uint32_t regen_idle, uint32_t sched_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw; // [NLDS][BLOCK]
   typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const f4v *lds_f4_ptr;
   RT_STACK_DECL(BLOCK, NLDS, st, lds_stack);
   const uint32_t lane = threadIdx.x & 63u;
+  // staging area of this wave behind the stacks; M0 values (LDS byte addresses) of the four instructions
+  uint32_t *stage_words = lds_raw + NLDS * BLOCK + (threadIdx.x >> 6) * (WF_COOP_BYTES / 4u);
+  const uint32_t stage_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32_ptr)stage_words);
+  const lds_f4_ptr my_rec = (lds_f4_ptr)(lds_u32_ptr)(stage_words + (lane & 3u) * (WF_COOP_STRIDE / 4u) + (lane >> 2) * 16u);
+  const uint32_t sub16 = (lane & 3u) * 16u;
 
   uint32_t state = WT_FETCH, slot = 0, traced = 0;
   V3 wo = v3(0.f, 0.f, 0.f), wd = v3(0.f, 0.f, 0.f); // the ray in world space
@@ -310,7 +331,61 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         const bool do1 = act == 1u, do3 = act == 3u;
         f4v qx, qy, qz;
         f2v qr;
-        {
+        if (COOP) {
+          const uint32_t rec_off = kind == 3u ? geom.tris_off + (ref & 0x7FFFFFFFu) * 48u : geom.pairs_off + ref * 64u;
+          uint32_t t0, t1, t2, t3, keep_m0;
+          unsigned long long saved, k0, k1, k2, k3;
+          asm volatile("s_mov_b64 %[sv], exec\n\t"
+                       "s_mov_b32 %[km0], m0\n\t"
+                       "s_mov_b64 exec, -1\n\t"
+                       "s_waitcnt lgkmcnt(0)\n\t" // the previous step's reads of the staging area are done
+                       "s_nop 3\n\t"
+                       "v_mov_b32_dpp %[t0], %[act] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_cmp_ne_u32_e32 vcc, 0, %[t0]\n\t"
+                       "v_add_u32_dpp %[t0], %[off], %[sub] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                       "s_mov_b64 %[k0], vcc\n\t"
+                       "v_mov_b32_dpp %[t1], %[act] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+                       "v_add_u32_dpp %[t1], %[off], %[sub] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                       "s_mov_b64 %[k1], vcc\n\t"
+                       "v_mov_b32_dpp %[t2], %[act] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_cmp_ne_u32_e32 vcc, 0, %[t2]\n\t"
+                       "v_add_u32_dpp %[t2], %[off], %[sub] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                       "s_mov_b64 %[k2], vcc\n\t"
+                       "v_mov_b32_dpp %[t3], %[act] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                       "v_cmp_ne_u32_e32 vcc, 0, %[t3]\n\t"
+                       "v_add_u32_dpp %[t3], %[off], %[sub] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                       "s_mov_b64 %[k3], vcc\n\t"
+                       "s_mov_b32 m0, %[l0]\n\t"
+                       "s_mov_b64 exec, %[k0]\n\t"
+                       "s_nop 0\n\t"
+                       "global_load_lds_dwordx4 %[t0], %[base]\n\t"
+                       "s_add_u32 m0, %[l0], 1040\n\t"
+                       "s_mov_b64 exec, %[k1]\n\t"
+                       "s_nop 0\n\t"
+                       "global_load_lds_dwordx4 %[t1], %[base]\n\t"
+                       "s_add_u32 m0, %[l0], 2080\n\t"
+                       "s_mov_b64 exec, %[k2]\n\t"
+                       "s_nop 0\n\t"
+                       "global_load_lds_dwordx4 %[t2], %[base]\n\t"
+                       "s_add_u32 m0, %[l0], 3120\n\t"
+                       "s_mov_b64 exec, %[k3]\n\t"
+                       "s_nop 0\n\t"
+                       "global_load_lds_dwordx4 %[t3], %[base]\n\t"
+                       "s_mov_b32 m0, %[km0]\n\t"
+                       "s_mov_b64 exec, %[sv]\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : [sv] "=&s"(saved), [km0] "=&s"(keep_m0), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3),
+                         [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                       : [act] "v"(act), [off] "v"(rec_off), [sub] "v"(sub16), [l0] "s"(stage_lds),
+                         [base] "s"(geom.base)
+                       : "memory", "vcc", "scc");
+          // the lane's own record, written by its quad (read by every lane: a conditional read makes the registers
+          // merges with an undefined value, which costs a second register set; idle lanes read stale bytes)
+          qx = my_rec[0], qy = my_rec[1], qz = my_rec[2];
+          const f4v qw = my_rec[3];
+          qr = f2v{qw.x, qw.y};
+        } else {
           // the shared, EXEC-narrowing load group of k_render_v8 (see there for why it is inline assembly)
           const uint32_t stride = kind == 3u ? 48u : 64u;
           const uint64_t base = kind == 3u ? (uint64_t)(uintptr_t)sc.tris : (uint64_t)(uintptr_t)sc.pairs;
@@ -488,8 +563,11 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buf
 #define RT_WF_MINW 6 // resident waves per SIMD the trace kernel is built for
 #endif
 #define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per workgroup
+// the cooperative-fetch build: 12 KiB of stacks + 16.25 KiB of staging per workgroup, 5 workgroups per CU
+#define RT_WF_COOP_MINW 5
+#define RT_WF_COOP_NLDS 12
 
-hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_uniforms &cam,
+hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
                                       const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
                                       hipStream_t stream) {
@@ -510,10 +588,21 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
     return hipErrorInvalidValue;
   float4 *accum = reinterpret_cast<float4 *>(d_accum);
   // knobs: bits 8-15 regeneration threshold of the trace kernel, 16-27 vote weights, 28-30 join code, 31 no fast slab
-  const uint32_t regen_idle = ((knobs >> 8) & 0xFFu) ? ((knobs >> 8) & 0xFFu) : 16u;
+  const uint32_t regen_idle = ((knobs >> 8) & 0x7Fu) ? ((knobs >> 8) & 0x7Fu) : 16u;
+  const bool coop = (knobs & 0x8000u) != 0u; // knob bit 15: quad-cooperative fetch instead of per-lane gathers
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
-  const size_t lds_bytes = (size_t)RT_WF_NLDS * RT_BLOCK * 4;
-  const uint64_t resident = (uint64_t)cus * (RT_WF_MINW * 4u / (RT_BLOCK / 64u));
+  const size_t lds_bytes = coop ? (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES
+                                : (size_t)RT_WF_NLDS * RT_BLOCK * 4;
+  const uint64_t resident = (uint64_t)cus * ((coop ? RT_WF_COOP_MINW : RT_WF_MINW) * 4u / (RT_BLOCK / 64u));
+#define RT_WF_TRACE(MODE)                                                                                              \
+  do {                                                                                                                 \
+    if (coop)                                                                                                          \
+      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true>), dim3(blocks), dim3(RT_BLOCK), \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched);                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS, false>), dim3(blocks), dim3(RT_BLOCK),     \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched);                            \
+  } while (0)
   auto span64 = [](uint64_t total) { // per-band share, a multiple of 64
     const uint64_t per = (total + WF_STRIPES - 1) / WF_STRIPES;
     return (uint32_t)((per + 63) / 64 * 64);
@@ -560,11 +649,9 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_camera_un
         const uint64_t need = ((uint64_t)ch.slots + WF_GRAB - 1) / WF_GRAB; // one wave per WF_GRAB slots at least
         const uint32_t blocks = (uint32_t)(need / (RT_BLOCK / 64) + 1 < resident ? need / (RT_BLOCK / 64) + 1 : resident);
         if (pc.aabb_mode == RT_AABB_RCP)
-          hipLaunchKernelGGL((k_wf_trace<RT_AABB_RCP, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
-                             lds_bytes, stream, sc, b, ch, d_counter, regen_idle, sched);
+          RT_WF_TRACE(RT_AABB_RCP);
         else
-          hipLaunchKernelGGL((k_wf_trace<RT_AABB_DIV, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS>), dim3(blocks), dim3(RT_BLOCK),
-                             lds_bytes, stream, sc, b, ch, d_counter, regen_idle, sched);
+          RT_WF_TRACE(RT_AABB_DIV);
         hipLaunchKernelGGL((k_wf_shade<false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
         if ((e = hipGetLastError()) != hipSuccess)
           return e;
