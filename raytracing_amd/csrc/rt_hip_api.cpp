@@ -83,7 +83,7 @@ struct rt_ctx {
   rt_wf_geom wf_geom_desc{};
   rt_wf_buffers wf{};
   uint64_t wf_tile_slots = 0;
-  uint32_t wf_slots = 1u << 23;          // paths in flight (rt_set_wavefront_budget)
+  uint32_t wf_slots = 1u << 25;          // paths in flight (rt_set_wavefront_budget): 32 Mi slots = 2.7 GiB of state
   uint64_t wf_sr_bytes = 10ull << 30;    // result buffer: 16 B per path of a sample chunk
   uint32_t *wf_h_ctrl = nullptr;
   rt_dev_scene dev{};
@@ -601,8 +601,22 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // Cornell box at 1 sample and depth 3 per frame — where every lane runs the same few steps and the plain
   // one-lane-per-pixel kernel is 1.3x faster (0.40 vs 0.53 ms at 1280x720).  All kernels give the same bits.
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
-  const uint32_t variant = !ctx->variant_auto ? ctx->variant
-                           : (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
+  // ... and for the keyed PCG RNG the wavefront pipeline (kernel 9) where it measured faster (tools/bench_wf.py, C3
+  // scene): launches of at least 1.2e8 paths (1920x1080 from 64 spp on) on images of up to 2^22 pixels (at 256 spp: 4.2 against 3.65
+  // Grays/s); with fewer paths its rounds are too short, and on larger images the megakernel's waves, which stay on
+  // their 8x8 tile, are the more coherent (3840x2160: 4.6 against 4.3 Grays/s).
+  uint32_t variant = ctx->variant;
+  if (ctx->variant_auto) {
+    const uint64_t px = (uint64_t)pc.image_width * (pc.row_end - pc.row_begin) / (pc.row_group_stride > 1u ? pc.row_group_stride : 1u);
+    const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
+    if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
+      variant = 0u;
+    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && paths >= 120000000ull &&
+             (uint64_t)pc.image_width * pc.image_height <= (1ull << 22))
+      variant = 9u;
+    else
+      variant = 8u;
+  }
   const bool wavefront = (variant & 0xFFu) == 9u;
   if (wavefront) {
     if (pc.rng_mode != RT_RNG_PCG)
@@ -895,8 +909,8 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
 }
 
 int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t result_bytes) {
-  if (!ctx || paths_in_flight < 256 || paths_in_flight > (1u << 28) || result_bytes < (1ull << 20))
-    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_wavefront_budget: 256 .. 2^28 paths, at least 1 MiB of results");
+  if (!ctx || paths_in_flight < 256 || paths_in_flight > (1u << 30) || result_bytes < (1ull << 20))
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_wavefront_budget: 256 .. 2^30 paths, at least 1 MiB of results");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->wf_slots = paths_in_flight;

@@ -127,6 +127,37 @@ def test_c3_dragon_full_size():
     r.shutdown()
 
 
+def test_c3_pcg_takes_the_wavefront_pipeline():
+    """C3 with the keyed PCG RNG at 64 spp per launch: the automatic choice is kernel 9 (the sample-parallel
+    wavefront pipeline, rt_wavefront.hip), and its image equals kernel 8's and — on the same 40 rows as above, at
+    4 spp — the oracle's, bit for bit; also with the quad-cooperative record fetch and with a budget that forces
+    sample chunks."""
+    import bench
+    w, h, depth = 1920, 1080, 8
+    r = R.Renderer(w, h, device=0)
+    cam, _ = bench.build_dragon_scene(R, r)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 64)
+    a = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
+    assert _last_kernel(r) == 9
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all()
+    assert _same(a, _launch(r, cam, 8))
+    assert _same(a, _launch(r, cam, 9 | (1 << 15)))
+    _ffi._check(_ffi.lib().rt_set_wavefront_budget(C.c_void_p(r.hip_context_handle()), 1 << 22, 1 << 30))  # 32 chunks
+    assert _same(a, _launch(r, cam, 9))
+    _ffi._check(_ffi.lib().rt_set_wavefront_budget(C.c_void_p(r.hip_context_handle()), 1 << 25, 10 << 30))
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 4)
+    b = _launch(r, cam, 9)
+    sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
+    want = np.zeros_like(b)
+    O.render(sa, camu, O.render_params(w, h, 0, 2, depth, rng_mode=T.RNG_PCG, row_begin=0, row_end=h, row_group_stride=33),
+             want, nthreads=16)
+    rows = sharding.interleaved_rows(0, 33, h)
+    assert _same(b[rows], want[rows])
+    r.shutdown()
+
+
 def test_c5_dragon_4k_defocus_pcg_sharded():
     """C5: the dragon scene at 3840x2160 with defocus blur (Random.slang:57-70 semantics) and the keyed PCG RNG,
     4 spp per launch; interleaved shares of three ranks stitch to the one-GPU image bit for bit, and 40 rows match

@@ -471,7 +471,9 @@ def test_hits_against_brute_force_on_a_dragon_submesh(ctx):
 
 
 # ---- kernel 9: the sample-parallel wavefront pipeline (rt_wavefront.hip), keyed PCG RNG only ----
-@pytest.mark.parametrize("knobs", [0, (4 << 8), (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24) | (5 << 28), 1 << 31])
+# knobs of kernel 9: bits 8-14 refill threshold, 15 quad-cooperative LDS-DMA record fetch, 16-30 as kernel 8, 31 no fast slab
+@pytest.mark.parametrize("knobs", [0, (4 << 8), (60 << 8) | (1 << 16) | (15 << 20) | (15 << 24) | (5 << 28), 1 << 31,
+                                   1 << 15, (1 << 15) | (1 << 31), (1 << 15) | (8 << 8) | (1 << 28)])
 @pytest.mark.parametrize("name,sqrt_spp,depth", [("cornell", 1, 3), ("cornell", 3, 8), ("mixed", 2, 8), ("teapot", 4, 8)])
 def test_wavefront_image_bit_exact(ctx, name, sqrt_spp, depth, knobs):
     make, camf = SCENES[name]
@@ -538,10 +540,11 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
         c.close()
 
 
-def test_wavefront_deep_stack_and_edge_scenes(ctx):
+@pytest.mark.parametrize("coop", [0, 1])
+def test_wavefront_deep_stack_and_edge_scenes(ctx, coop):
     """Kernel 9's trace kernel keeps 16 stack entries in LDS: the 38-instance chain drives it to 37; scenes outside the
     fast slab preconditions take its literal slab test."""
-    ctx.set_kernel_variant(9)
+    ctx.set_kernel_variant(9 | (coop << 15))
     try:
         sc = _chain_scene().build()
         ctx.upload_scene(sc)
