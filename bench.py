@@ -5,9 +5,12 @@ Workload (N=1): dragon-class mesh (procedural stand-in, 870,400 triangles, seed
 1234 — the reference's dragon.obj is missing from its snapshot) on a ground
 plane under the sky gradient, 1920x1080, 256 spp per step (one launch of the
 path-tracing megakernel with a 16x16 stratified grid), max_depth 8, reference
-slab arithmetic (division); `--rng wang` (default) is the reference's sequential
-Wang hash, `--rng pcg` the keyed PCG that north_star names.  A step is one full
-frame; successive steps are successive progressive frames (RayTracing.slang:176-179).
+slab arithmetic (division).  `--rng pcg` (default) is the keyed PCG RNG that north_star
+names — every draw a hash of (pixel, sample, bounce, dimension) — which lets the library
+run its sample-parallel wavefront pipeline (kernel 9); `--rng wang` is the reference's
+sequential Wang hash, which admits only the megakernel (kernel 8): the default run
+measures it too and reports it under "wang_rng".  A step is one full frame; successive
+steps are successive progressive frames (RayTracing.slang:176-179).
 
 N>1 (one process per GPU, RCCL): the scene is replicated and every frame is cut
 into groups of 8 rows dealt round-robin to the ranks (`--shard interleave`, the
@@ -76,7 +79,7 @@ def product_layout_bytes_per_ray(cn, spp_per_launch):
     return (trav + shade) / rays, 32.0 / spp_per_launch
 
 
-KERNEL_NAMES = {0: "k_render_v0", 8: "k_render_v8", 9: "k_wf_*"}
+KERNEL_NAMES = {0: "k_render_v0", 8: "k_render_v8", 9: "k_wf_trace + k_wf_shade + k_wf_resolve (kernel 9)"}
 
 
 def host_threads(requested):
@@ -113,7 +116,8 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step (perfect square)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
-    ap.add_argument("--rng", choices=["wang", "pcg"], default="wang")
+    ap.add_argument("--rng", choices=["wang", "pcg"], default="pcg")
+    ap.add_argument("--no-wang", action="store_true", help="N=1, --rng pcg: skip the extra measurement with the reference's RNG")
     ap.add_argument("--defocus", action="store_true", help="the C5 camera: thin lens instead of the pinhole")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0xFFFFFFFF,
                     help="kernel variant (default: RT_KERNEL_VARIANT_AUTO, the library's choice)")
@@ -261,6 +265,28 @@ def main():
     else:
         elapsed_max, rays_total = elapsed, rays_local
 
+    # N=1, PCG: the same workload with the reference's own RNG (sequential Wang hash: megakernel only), same timing rules
+    wang = None
+    if world == 1 and args.rng == "pcg" and not args.no_wang:
+        r.set_option(R.OPT_RNG_MODE, T.RNG_WANG)
+        r.reset_accumulation()
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _ffi._check(L.rt_reset_stats(ctx))
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        tw = time.perf_counter() - tw
+        sw = _ffi.Stats()
+        _ffi._check(L.rt_get_stats(ctx, C.byref(sw)))
+        wang = {"value": sw.rays_traced / tw / 1e6, "unit": "Mrays/s", "ms_per_step": tw / args.steps * 1e3,
+                "kernel": KERNEL_NAMES.get(sw.last_kernel, "?"), "kernel_ms_per_launch": sw.total_kernel_ms / max(sw.launches, 1),
+                "note": "same scene, size, spp and depth with rng_mode = RT_RNG_WANG (Random.slang:7-19)"}
+        r.set_option(R.OPT_RNG_MODE, rng_mode)
+        r.reset_accumulation()
+
     # N>1 parity: rank 0 re-renders, on its own, a sample of row groups that OTHER ranks rendered, over all
     # warmup + timed frames, and compares them with the gathered image bit for bit
     parity = None
@@ -353,9 +379,11 @@ def main():
         # the PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh) taken on the default workload; the figure
         # is read from their committed summary, not measured in this process: other shapes report none
         if world == 1 and os.path.exists(tpath) and \
-                (W, H, args.spp, args.depth, args.aabb, args.rng, args.defocus) == (1920, 1080, 256, 8, "div", "wang", False):
+                (W, H, args.spp, args.depth, args.aabb, args.defocus) == (1920, 1080, 256, 8, "div", False):
             try:
                 tdoc = json.load(open(tpath))
+                if tdoc.get("rng", "wang") != args.rng:
+                    raise KeyError("taken with another RNG mode")
                 traffic = tdoc.get("hbm_bytes_per_launch")
                 traffic_source = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   f"tools/profile_pmc.sh, kernel {tdoc.get('kernel')}, taken at commit "
@@ -404,7 +432,7 @@ def main():
         "kernel_ms_per_launch_by_rank": per_rank_kernel_ms,
         "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * (1 if strong or world == 1 else world))),
         "rays_per_step": rays_total / args.steps, "kernel_ms_per_launch": kernel_ms,
-        "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity,
+        "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity, "wang_rng": wang,
         "commit": git_commit(),
     }
     print(json.dumps(out), flush=True)
