@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Mechanical check of the invariant behind k_render_v8's uncounted loads (rt_kernels.hip, joined pair / leaf step).
+"""Mechanical check of the invariant behind the uncounted loads of k_render_v8 (rt_kernels.hip) and k_wf_trace
+(rt_wavefront.hip, same joined pair / leaf step).
 
 The kernel issues its pair / triangle loads in inline assembly that the compiler does not count; the matching
 `s_waitcnt vmcnt(0)` sits in separate asm statements at the head of the two consuming sections.  That is only
@@ -7,11 +8,11 @@ correct while the compiler places no instruction that reads or writes the four d
 the load group and those waits (a copy, a spill), and while the kernel has no register spills at all (a spill store
 of such a register would read it in flight).  This script reads the device assembly (hipcc -S) and fails if
 
-  * a k_render_v8 instance reports vector register spills, or
+  * a k_render_v8 / k_wf_trace instance reports vector register spills, or
   * on any straight-line stretch between RT_V8_LOADS_END and the RT_V8_WAIT_* markers an instruction names a
     destination register of the load group before an `s_waitcnt vmcnt(0)` has been passed in that basic block.
 
-Usage: check_v8_asm.py rt_kernels.s   (exit status 1 on a violation)."""
+Usage: check_v8_asm.py rt_kernels.s [rt_wavefront.s ...]   (exit status 1 on a violation)."""
 import re
 import sys
 
@@ -39,7 +40,7 @@ def check(path):
     i = 0
     while i < len(lines):
         ln = lines[i]
-        m = re.match(r"^(_Z\w*k_render_v8\w*):", ln)
+        m = re.match(r"^(_Z\w*(?:k_render_v8|k_wf_trace)\w*):", ln)
         if m:
             kernel = m.group(1)
         if "RT_V8_LOADS_BEGIN" in ln:
@@ -78,7 +79,7 @@ def check(path):
             i = j
         i += 1
     # register spills, from the kernel descriptors' comment block / metadata
-    for m in re.finditer(r"\.name:\s+(_Z\w*k_render_v8\w*)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)",
+    for m in re.finditer(r"\.name:\s+(_Z\w*(?:k_render_v8|k_wf_trace)\w*)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)",
                          "\n".join(lines)):
         if int(m.group(3)):  # scalar spills go to lanes of a reserved VGPR (v_writelane), never to memory: no hazard
             errors.append(f"{m.group(1)}: vector register spills ({m.group(3)})")
@@ -90,8 +91,11 @@ def check(path):
 
 
 if __name__ == "__main__":
-    n, errs = check(sys.argv[1])
-    for e in errs:
-        print("check_v8_asm: " + e, file=sys.stderr)
-    print(f"check_v8_asm: {n} load group(s) checked, {len(errs)} violation(s)")
-    sys.exit(1 if errs else 0)
+    bad = 0
+    for path in sys.argv[1:]:
+        n, errs = check(path)
+        for e in errs:
+            print("check_v8_asm: " + e, file=sys.stderr)
+        print(f"check_v8_asm: {path}: {n} load group(s) checked, {len(errs)} violation(s)")
+        bad += len(errs)
+    sys.exit(1 if bad else 0)
