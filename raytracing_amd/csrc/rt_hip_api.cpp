@@ -110,6 +110,15 @@ struct rt_ctx {
   bool variant_auto = true; // rt_render chooses between variants 8 and 0 (RT_KERNEL_VARIANT_AUTO)
   uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
   uint32_t last_kernel = 0; // kernel of the most recent rt_render
+  // Automatic choice between kernels 8 and 9 for keyed-PCG launches (rt_render): both are run once on a launch shape
+  // and the faster one keeps it.  `scene_epoch` counts rt_upload_scene / rt_update_instances.
+  struct Tune {
+    uint32_t key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t phase = 0; // 0 nothing measured, 1 kernel 9 measured, 2 both measured: `choice` holds
+    float ms9 = 0.f, ms8 = 0.f;
+    uint32_t choice = 9;
+  } tune;
+  uint32_t scene_epoch = 0;
   uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
   // timing
   std::vector<EventPair> pending, free_events;
@@ -306,6 +315,7 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.cache_pairs = cached;
   ctx->pair_count = (uint32_t)all.size();
   ctx->wf_geom_dirty = true;
+  ++ctx->scene_epoch; // a measured kernel choice (rt_render) does not carry over
   ctx->dev.flags = moderate ? RT_SCENE_BOXES_MODERATE : 0u;
   return RT_OK;
 }
@@ -605,16 +615,33 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // scene): launches of at least 1.2e8 paths (1920x1080 from 64 spp on) on images of up to 2^22 pixels (at 256 spp: 4.2 against 3.65
   // Grays/s); with fewer paths its rounds are too short, and on larger images the megakernel's waves, which stay on
   // their 8x8 tile, are the more coherent (3840x2160: 4.6 against 4.3 Grays/s).
+  // Which of the two wins depends on the scene, not only on the launch shape — closed Cornell box (every path runs to
+  // full depth, short traversals): kernel 8 9.2 against 6.6 Grays/s; teapot under the sky 6.0 against 8.3; 2025
+  // instances 3.2 against 4.05 (tools/bench_configs.py, 1080p) — so an eligible shape is MEASURED: its first launch
+  // runs kernel 9, its second kernel 8, and from the third on the faster of the two.  The images are the same bits
+  // either way.  The measurement is repeated when the scene, the instances or the launch shape change.
   uint32_t variant = ctx->variant;
+  uint32_t tuning = 0; // 9 / 8: this launch is the timed trial of that kernel
   if (ctx->variant_auto) {
     const uint64_t px = (uint64_t)pc.image_width * (pc.row_end - pc.row_begin) / (pc.row_group_stride > 1u ? pc.row_group_stride : 1u);
     const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
     else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && paths >= 120000000ull &&
-             (uint64_t)pc.image_width * pc.image_height <= (1ull << 22))
-      variant = 9u;
-    else
+             (uint64_t)pc.image_width * pc.image_height <= (1ull << 22)) {
+      const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
+                               pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
+      if (memcmp(key, ctx->tune.key, sizeof key) != 0) {
+        memcpy(ctx->tune.key, key, sizeof key);
+        ctx->tune.phase = 0;
+      }
+      if (ctx->tune.phase == 0)
+        variant = tuning = 9u;
+      else if (ctx->tune.phase == 1)
+        variant = tuning = 8u;
+      else
+        variant = ctx->tune.choice;
+    } else
       variant = 8u;
   }
   const bool wavefront = (variant & 0xFFu) == 9u;
@@ -683,7 +710,20 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     return fail(RT_ERR_HIP, std::string("rt_render: launch failed: ") + hipGetErrorString(le));
   }
   ctx->last_kernel = variant & 0xFFu;
-  return end_timed(ctx, ev);
+  rc = end_timed(ctx, ev);
+  if (rc == RT_OK && tuning) { // a trial launch: wait for it and keep its time
+    if ((rc = drain_events(ctx)) != RT_OK)
+      return rc;
+    if (tuning == 9u) {
+      ctx->tune.ms9 = (float)ctx->last_ms;
+      ctx->tune.phase = 1;
+    } else {
+      ctx->tune.ms8 = (float)ctx->last_ms;
+      ctx->tune.choice = ctx->tune.ms9 <= ctx->tune.ms8 ? 9u : 8u;
+      ctx->tune.phase = 2;
+    }
+  }
+  return rc;
 }
 
 int rt_trace_closest_device(rt_ctx *ctx, const void *device_rays, uint64_t n, void *device_hits,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel 9 (wavefront pipeline) against kernel 8 in PCG mode on the bench scene: Mrays/s over knobs and budgets.
-Usage: bench_wf.py [spp] [WxH]  (defaults 64, 1920x1080)"""
+Usage: bench_wf.py [spp] [WxH] [variant:slots:sr_GiB ...]  (defaults 64, 1920x1080); RT_SCENE=dragon|cornell|teapot"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -11,7 +11,12 @@ W, H = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1920x1080").spli
 cases = [tuple(int(x, 0) for x in a.split(":")) for a in sys.argv[3:]] or \
     [(8, 0, 0), (9, 1 << 23, 10), (9, 1 << 20, 10), (9, 1 << 25, 10), (9 | (4 << 8), 1 << 23, 10), (9 | (32 << 8), 1 << 23, 10)]
 r = R.Renderer(W, H, device=0)
-cam, n = bench.build_dragon_scene(R, r)
+scene = os.environ.get("RT_SCENE", "dragon")
+if scene == "dragon":
+    cam, n = bench.build_dragon_scene(R, r)
+else:
+    from tests import _scenes as S
+    cam, _ = r.load_scene_file(os.path.join(S.ASSETS, "scenes", scene + ".json"))
 r.set_option(R.OPT_SAMPLES_PER_PIXEL, spp)
 r.set_option(R.OPT_MAX_DEPTH, 8)
 r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
