@@ -316,3 +316,177 @@ def test_item_8_equal_distances_keep_child1_first_and_item_9_later_equal_t_wins(
         got = py_tlas_intersect(sc, ray["origin"][:3].astype(F), ray["direction"][:3].astype(F), F(1e-4), F(1000))
         assert got is not None and (got[1], got[4]) == (int(want["tri_id"][k]), int(want["inst_id"][k]))
         assert got[0] == F(1.0)
+
+
+# --------------------------------- compute_main (RayTracing.slang:62-181, Material.slang, Random.slang), items 10-16
+
+def wang_rand(state):  # Random.slang:7-19; state is a one-element list (inout uint seed)
+    M = 0xFFFFFFFF
+    s = state[0]
+    s = ((s ^ 61) ^ (s >> 16)) & M
+    s = (s * 9) & M
+    s = s ^ (s >> 4)
+    s = (s * 0x27D4EB2D) & M
+    s = s ^ (s >> 15)
+    state[0] = s
+    return F(s) / F(4294967296.0)       # item 13: float(0xFFFFFFFF) rounds to 2^32 -> exactly 1.0
+
+
+def sincos_det(a):  # the one deliberate deviation: sin/cos are the repository's fixed definitions
+    import ctypes as C
+    s, c = C.c_float(), C.c_float()
+    O.lib().orc_sincos(F(a), C.byref(s), C.byref(c))
+    return F(s.value), F(c.value)
+
+
+def normalize3(v):
+    return v * (F(1) / np.sqrt(dot3(v, v)))
+
+
+def rand_unit_vector(state):  # Random.slang:34-41 — draw order z, then a (item 12)
+    z = F(-1) + F(F(1) - F(-1)) * wang_rand(state)
+    a = wang_rand(state) * F(F(2) * F(3.14159265359))
+    r = np.sqrt(F(1) - z * z)
+    s, c = sincos_det(a)
+    return np.array([r * c, r * s, z], F)
+
+
+def reflect3(i, n):
+    return i - F(F(2) * dot3(n, i)) * n
+
+
+HIT_TYPES = set()   # material types the restated shader has met (the test wants all four)
+
+
+def py_shade_pixel(sc, cam, x, y, width, frame_index, sqrt_spp, max_depth, prev, accum_count):
+    state = [((x * 1973) ^ (y * 9277) ^ (frame_index * 26699)) & 0xFFFFFFFF]      # RayTracing.slang:71-72
+    recip = F(1) / F(sqrt_spp)                                                      # Renderer.cpp:628
+    scale = F(1) / F(sqrt_spp * sqrt_spp)                                           # Renderer.cpp:626
+    p00, du, dv, center = (np.array(list(v)[:3], F) for v in (cam.pixel00_loc, cam.pixel_delta_u, cam.pixel_delta_v, cam.camera_center))
+    radiance = np.zeros(3, F)
+    for s_j in range(sqrt_spp):
+        for s_i in range(sqrt_spp):
+            jx = F(F(F(s_i) + wang_rand(state)) * recip) - F(0.5)                   # item 12: jitter x, then y
+            jy = F(F(F(s_j) + wang_rand(state)) * recip) - F(0.5)
+            sample = (p00 + F(F(x) + jx) * du) + F(F(y) + jy) * dv
+            o, d = center, normalize3(sample - center)                              # item 11: primary direction normalised
+            att, rad = np.ones(3, F), np.zeros(3, F)
+            for _ in range(max_depth):
+                hit = py_tlas_intersect(sc, o, d, F(0.0001), F(1000))
+                if hit is None:
+                    u = normalize3(d)                                               # item 14: normalised AGAIN for the sky
+                    a = F(0.5) * F(u[1] + F(1))
+                    sky = np.array([0.7, 0.7, 0.7], F) * F(F(1) - a) + np.array([0.5, 0.7, 1.0], F) * a
+                    rad = rad + att * sky
+                    break
+                t, tri, bu, bv, inst_id = hit
+                inst, sh = sc.instances[inst_id], sc.tri_shading[tri]
+                # item 10: the hit point is computed with the OBJECT-space ray, then moved by `transform`
+                oo = mat_vec(inst["inv_transform"], np.array([o[0], o[1], o[2], 1], F))[:3]
+                dd = mat_vec(inst["inv_transform"], np.array([d[0], d[1], d[2], 0], F))[:3]
+                p_obj = oo + t * dd
+                alpha = F(F(1) - bu) - bv
+                ln = normalize3((alpha * sh["n0"][:3] + bu * sh["n1"][:3]) + bv * sh["n2"][:3])
+                rows = inst["inv_transform"].reshape(4, 4)                          # transpose(inv_transform) * (n, 0)
+                wn = (rows[:3, 0] * ln[0] + rows[:3, 1] * ln[1]) + (rows[:3, 2] * ln[2] + rows[:3, 3] * F(0))
+                wn = normalize3(wn.astype(F))
+                front = dot3(d, wn) < 0
+                n = wn if front else -wn
+                uvx = F(F(alpha * sh["uv0"][0]) + F(bu * sh["uv1"][0])) + F(bv * sh["uv2"][0])
+                uvy = F(F(alpha * sh["uv0"][1]) + F(bu * sh["uv1"][1])) + F(bv * sh["uv2"][1])
+                p = mat_vec(inst["transform"], np.array([p_obj[0], p_obj[1], p_obj[2], 1], F))[:3]
+                mtype, mindex = int(inst["mat_type"]), int(inst["mat_index"])
+                HIT_TYPES.add(mtype)
+                emission, scattered = np.zeros(3, F), True
+                if mtype == T.MATERIAL_LAMBERT:                                     # Material.slang:23-37
+                    nd = n + rand_unit_vector(state)                                # item 11: NOT normalised
+                    if abs(nd[0]) < F(1e-8) and abs(nd[1]) < F(1e-8) and abs(nd[2]) < F(1e-8):
+                        nd = n
+                    off, tw, th = (int(v) for v in list(sc.textures[int(sc.lamberts[mindex])])[:3])
+                    fu, fv = np.floor(uvx * F(tw)), np.floor(uvy * F(th))           # nearest, repeat
+                    ix = int(fu - np.floor(fu / F(tw)) * F(tw))
+                    iy = int(fv - np.floor(fv / F(th)) * F(th))
+                    px = sc.texels[off + 4 * (iy * tw + ix):][:3]
+                    m_att = np.array([F(px[0]) / F(255), F(px[1]) / F(255), F(px[2]) / F(255)], F)   # item 17: UNORM decode
+                elif mtype == T.MATERIAL_METAL:                                     # Material.slang:39-57
+                    m = sc.metals[mindex]
+                    nd = reflect3(d, n) + m[3] * rand_unit_vector(state)            # item 11: NOT normalised
+                    m_att = m[:3].astype(F)
+                elif mtype == T.MATERIAL_DIELECTRIC:                                # Material.slang:77-100
+                    ior = F(sc.dielectrics[mindex])
+                    ri = F(1) / ior if front else ior
+                    ud = normalize3(d)                                              # item 11: incoming direction normalised
+                    cos_t = fmin(dot3(-ud, n), F(1))
+                    sin_t = np.sqrt(fmax(F(0), F(1) - cos_t * cos_t))
+                    reflects = ri * sin_t > F(1)
+                    if not reflects:                                                # `||` short-circuits: the draw is skipped
+                        r0 = F(F(1) - ri) / F(F(1) + ri)
+                        r0 = r0 * r0
+                        xx = F(1) - cos_t
+                        x2 = xx * xx
+                        reflects = F(r0 + F(F(1) - r0) * F(F(x2 * x2) * xx)) > wang_rand(state)    # item 12: ONE draw
+                    if reflects:
+                        nd = reflect3(ud, n)
+                    else:
+                        ct = fmin(dot3(-ud, n), F(1))
+                        perp = ri * (ud + ct * n)
+                        nd = perp + F(-np.sqrt(abs(F(1) - dot3(perp, perp)))) * n
+                    m_att = np.ones(3, F)
+                else:                                                               # emissive: no draw, path ends
+                    emission, scattered = sc.emissives[mindex][:3].astype(F), False
+                rad = rad + att * emission
+                if not scattered:
+                    break
+                att = att * m_att
+                o, d = p.astype(F), nd.astype(F)
+            radiance = radiance + rad
+    radiance = radiance * scale
+    return (prev * F(accum_count) + radiance) / F(accum_count + 1)                  # item 15: uint -> float, running mean
+
+
+@pytest.mark.parametrize("scene", ["cornell", "mixed"])
+def test_items_10_to_15_second_restatement_of_compute_main(scene):
+    sc = {"cornell": S.cornell_builtin, "mixed": S.mixed_scene}[scene]().build()
+    w, h, sqrt_spp, depth = 16, 9, 2, 4
+    cam = {"cornell": S.cornell_camera, "mixed": S.mixed_camera}[scene](w, h)
+    img0 = O.render(sc, cam, O.render_params(w, h, 0, sqrt_spp, depth))
+    img1 = img0.copy()
+    O.render(sc, cam, O.render_params(w, h, 1, sqrt_spp, depth), img1)               # second progressive frame
+    with np.errstate(all="ignore"):
+        for (x, y) in [(0, 0), (3, 2), (8, 4), (5, 7), (12, 6), (15, 8), (9, 1), (2, 5), (11, 3), (7, 8)]:
+            got0 = py_shade_pixel(sc, cam, x, y, w, 0, sqrt_spp, depth, np.zeros(3, F), 0)
+            assert np.array_equal(got0.astype(F).view(np.uint32), img0[y, x, :3].view(np.uint32)), (x, y)
+            got1 = py_shade_pixel(sc, cam, x, y, w, 1, sqrt_spp, depth, got0.astype(F), 1)
+            assert np.array_equal(got1.astype(F).view(np.uint32), img1[y, x, :3].view(np.uint32)), (x, y)
+    assert (img0[..., 3] == 1).all()
+    if scene == "mixed":
+        assert HIT_TYPES == {T.MATERIAL_LAMBERT, T.MATERIAL_METAL, T.MATERIAL_DIELECTRIC, T.MATERIAL_EMISSIVE}
+
+
+def test_item_18_tlas_leaf_bounds_come_from_the_double_inverse():
+    """TLAS.cpp:22-23 bounds a leaf with inverse(inv_transform), not with `transform`: the builder must not read the
+    `transform` field at all, and for a rotated, scaled instance the two matrices differ in the last bits."""
+    r = S.mixed_scene()
+    clean = r.build().tlas_nodes.copy()
+    differ = 0
+    for k in range(len(r.instances)):
+        back = O.mat4_inverse(r.instances["inv_transform"][k])
+        differ += int(not np.array_equal(back, r.instances["transform"][k]))
+    assert differ > 0                                             # otherwise the scene could not tell the readings apart
+    kept = r.instances["transform"].copy()
+    r.instances["transform"][:] = F(123.0)                        # garbage: must not matter
+    assert r.build().tlas_nodes.tobytes() == clean.tobytes()
+    r.instances["transform"][:] = kept
+    # and the leaf box is the box of the 8 corners of the BLAS root box moved by that double inverse
+    sc = r.build()
+    leaf = next(n for n in sc.tlas_nodes[: sc.tlas_node_count] if n["left_right"] == 0 and sc.tlas_node_count > 1)
+    inst = sc.instances[int(leaf["blas_instance_idx"])]
+    root = sc.bvh_nodes[int(sc.blas[int(inst["blas_id"])]["bvh_nodes_offset"])]
+    m = O.mat4_inverse(inst["inv_transform"])
+    lo, hi = np.full(3, INF, F), np.full(3, -INF, F)
+    for c in range(8):
+        corner = np.array([(root["aabb_max"] if c & 1 else root["aabb_min"])[0], (root["aabb_max"] if c & 2 else root["aabb_min"])[1],
+                           (root["aabb_max"] if c & 4 else root["aabb_min"])[2], 1], F)
+        p = mat_vec(m, corner)[:3]
+        lo, hi = np.minimum(lo, p), np.maximum(hi, p)
+    assert np.array_equal(leaf["aabb_min"], lo) and np.array_equal(leaf["aabb_max"], hi)

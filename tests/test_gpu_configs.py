@@ -128,6 +128,19 @@ def test_c3_dragon_full_size():
     r.shutdown()
 
 
+def test_spp_is_truncated_to_a_square_like_the_reference():
+    """SURVEY.md App. C #16: sqrt_spp = u32(sqrt(spp)) (Renderer.cpp:625) — 10 samples per pixel render 3 x 3."""
+    r = R.Renderer(96, 54, device=0)
+    cam, _ = r.load_scene_file(os.path.join(SCENES, "teapot.json"))
+    r.set_option(R.OPT_MAX_DEPTH, 4)
+    imgs = {}
+    for spp in (9, 10, 15, 16):
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, spp)
+        imgs[spp] = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
+    assert _same(imgs[9], imgs[10]) and _same(imgs[9], imgs[15]) and not _same(imgs[9], imgs[16])
+    r.shutdown()
+
+
 def test_automatic_choice_times_both_kernels_once_per_scene_and_shape():
     """Keyed PCG, 1920x1080, 64 spp: a context that was given no kernel runs kernel 9 on the first launch of a shape,
     kernel 8 on the second and the faster of the two afterwards; a new scene or shape starts over; all the same bits.
