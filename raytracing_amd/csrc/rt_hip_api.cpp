@@ -702,7 +702,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     return rc;
   const hipError_t le =
       wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->wf_geom_desc, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                                             ctx->wf, ctx->wf_h_ctrl, variant, ctx->cus, ctx->stream)
+                                             ctx->wf, ctx->wf_h_ctrl, variant | (ctx->variant_auto ? 0u : ctx->regen_idle << 8),
+                                             ctx->cus, ctx->stream) // bits 8-15: kernel 9's own knobs
                 : rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
                                    effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
   if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent
