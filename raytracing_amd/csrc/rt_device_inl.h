@@ -533,8 +533,6 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, uint32_t flags, bo
   V3 outward = normalize(mul_cols(r0, r1, r2, r3, local_normal, 0.0f));
   bool front_face = dot(p.d, outward) < 0.f; // HitRecord.slang:17-21
   V3 normal = front_face ? outward : neg(outward);
-  float uvx = (alpha * sh.uv0[0] + hit.u * sh.uv1[0]) + hit.v * sh.uv2[0];
-  float uvy = (alpha * sh.uv0[1] + hit.u * sh.uv1[1]) + hit.v * sh.uv2[1];
   V3 pw = mul_cols(ld3(T + 0), ld3(T + 4), ld3(T + 8), ld3(T + 12), p_obj, 1.f);
 
   const uint32_t mtype = inst.mtype;
@@ -548,10 +546,15 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, uint32_t flags, bo
     if (near_zero(sd))
       sd = normal;
     out_d = sd;
-    // a 1x1 texture returns its texel for every uv (NaN included): decoded at upload into param
-    matt = (inst.tex_w == 1u && inst.tex_h == 1u)
-               ? v3(mparam.x, mparam.y, mparam.z)
-               : sample_albedo(sc, inst.tex_offset, inst.tex_w, inst.tex_h, uvx, uvy);
+    // a 1x1 texture returns its texel for every uv (NaN included): decoded at upload into param, and the triangle's
+    // uvs (32 of the record's 80 bytes) are not even fetched
+    if (inst.tex_w == 1u && inst.tex_h == 1u) {
+      matt = v3(mparam.x, mparam.y, mparam.z);
+    } else {
+      const float uvx = (alpha * sh.uv0[0] + hit.u * sh.uv1[0]) + hit.v * sh.uv2[0];
+      const float uvy = (alpha * sh.uv0[1] + hit.u * sh.uv1[1]) + hit.v * sh.uv2[1];
+      matt = sample_albedo(sc, inst.tex_offset, inst.tex_w, inst.tex_h, uvx, uvy);
+    }
     scattered = true;
   } else if (mtype == RT_MATERIAL_METAL) { // Material.slang:39-57
     const float4 m = mparam;

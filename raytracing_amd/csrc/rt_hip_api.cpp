@@ -627,7 +627,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
-    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && paths >= 120000000ull &&
+    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 120000000ull &&
              (uint64_t)pc.image_width * pc.image_height <= (1ull << 22)) {
       const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
                                pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
@@ -649,6 +649,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     if (pc.rng_mode != RT_RNG_PCG)
       return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
                                       "state runs through a pixel's samples, so they cannot be traced side by side");
+    if (pc.max_depth >= (1u << 29))
+      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^29)");
     // HBM state of the pipeline, sized for this launch shape and kept for the next one
     const uint32_t rows = rt_virtual_rows(pc);
     const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;

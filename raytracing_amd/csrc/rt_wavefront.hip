@@ -42,6 +42,15 @@ enum : uint32_t {
   WF_CTRL_WORDS = WF_ALIVE + WF_STRIPES * WF_PAD
 };
 #define WF_DEAD 0xFFFFFFFFu // depth word of a slot without a path
+// Depth word bit 30: the slot's `rad` entry holds the path's sample radiance.  Clear = the radiance is +0, +0, +0 and
+// `rad` is neither written nor read — the state of practically every path until its last bounce, since only an emitter
+// or the sky adds to it (RayTracing.slang:151,165) and both end the path; a path whose radiance is anything else (a
+// NaN from an infinite attenuation times a zero emission) sets the bit and goes through `rad`.  Saves 32 of the
+// ~230 B of HBM traffic per ray in the shade kernel.  (max_depth >= 2^30 is refused by the launcher.)
+#define WF_HAS_RAD 0x40000000u
+// Depth word bit 29: the slot's `att` entry holds the path's attenuation.  Clear = a fresh path, attenuation 1, 1, 1
+// (RayTracing.slang:88): not written by the regeneration, not read by the path's first shade.
+#define WF_HAS_ATT 0x20000000u
 
 struct WfChunk {
   uint32_t s0;       // first sample of the chunk
@@ -112,9 +121,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
           camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
           b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
           b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
-          b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
-          b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
-          want = false;
+          want = false; // (attenuation 1 and sample radiance +0: WF_HAS_ATT / WF_HAS_RAD clear, nothing to store)
           started = true;
         }
       }
@@ -141,7 +148,11 @@ __global__ void __launch_bounds__(RT_BLOCK)
     const float4 rd = b.ray_d[slot];
     uint32_t depth = __float_as_uint(rd.w);
     if (depth != WF_DEAD) {
-      const float4 ro = b.ray_o[slot], at = b.att[slot], ra = b.rad[slot], h = b.hit[slot];
+      const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
+      depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
+      const float4 ro = b.ray_o[slot], h = b.hit[slot];
+      const float4 at = has_att ? b.att[slot] : make_float4(1.f, 1.f, 1.f, 0.f);
+      const float4 ra = has_rad ? b.rad[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t id = __float_as_uint(ro.w);
       uint32_t x, y, sample;
       wf_pixel_of(pc, ch, id, x, y, sample);
@@ -158,10 +169,13 @@ __global__ void __launch_bounds__(RT_BLOCK)
       const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
       ++depth;
       if (scattered && depth < pc.max_depth) {
+        const bool keep_rad = (__float_as_uint(p.sample_radiance.x) | __float_as_uint(p.sample_radiance.y) |
+                               __float_as_uint(p.sample_radiance.z)) != 0u; // anything but +0, +0, +0
         b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
-        b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth));
+        b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth | WF_HAS_ATT | (keep_rad ? WF_HAS_RAD : 0u)));
         b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
-        b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        if (keep_rad)
+          b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
         goes_on = true;
       } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
         b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
@@ -574,7 +588,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   const uint32_t rows = rt_virtual_rows(pc);
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG)
+  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG || pc.max_depth >= WF_HAS_ATT)
     return hipErrorInvalidValue;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint64_t tile_slots = (uint64_t)tiles_x * ((rows + 7u) >> 3) * 64u;
@@ -588,7 +602,8 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
     return hipErrorInvalidValue;
   float4 *accum = reinterpret_cast<float4 *>(d_accum);
   // knobs: bits 8-15 regeneration threshold of the trace kernel, 16-27 vote weights, 28-30 join code, 31 no fast slab
-  const uint32_t regen_idle = ((knobs >> 8) & 0x7Fu) ? ((knobs >> 8) & 0x7Fu) : 16u;
+  // default 24 idle lanes (C3, 256 spp: 4 -> 308 ms, 8 -> 301, 16 -> 289, 24 -> 282, 32 -> 292, 48 -> 327 per launch)
+  const uint32_t regen_idle = ((knobs >> 8) & 0x7Fu) ? ((knobs >> 8) & 0x7Fu) : 24u;
   const bool coop = (knobs & 0x8000u) != 0u; // knob bit 15: quad-cooperative fetch instead of per-lane gathers
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
   const size_t lds_bytes = coop ? (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES
