@@ -83,7 +83,8 @@ struct rt_ctx {
   rt_wf_geom wf_geom_desc{};
   rt_wf_buffers wf{};
   uint64_t wf_tile_slots = 0;
-  uint32_t wf_slots = 1u << 25;          // paths in flight (rt_set_wavefront_budget): 32 Mi slots = 2.7 GiB of state
+  uint32_t wf_slots = 1u << 26;          // most paths in flight (rt_set_wavefront_budget): 64 Mi slots = 5.6 GB of state
+  uint32_t wf_capacity = 0;              // slots the state allocation holds
   uint64_t wf_sr_bytes = 10ull << 30;    // result buffer: 16 B per path of a sample chunk
   uint32_t *wf_h_ctrl = nullptr;
   rt_dev_scene dev{};
@@ -655,19 +656,32 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint32_t rows = rt_virtual_rows(pc);
     const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
     const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
-    uint64_t want_slots = tile_slots * spp < ctx->wf_slots ? tile_slots * spp : ctx->wf_slots;
+    // paths in flight: an eighth of the chunk's paths (measured on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
+    // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
+    uint64_t chunk_paths = tile_slots * spp;
+    if (chunk_paths * 16 > ctx->wf_sr_bytes)
+      chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
+    if (chunk_paths < tile_slots)
+      chunk_paths = tile_slots;
+    uint64_t want_slots = (chunk_paths / 8 + 255) / 256 * 256;
+    if (want_slots < (1u << 20))
+      want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
+    if (want_slots > ctx->wf_slots)
+      want_slots = ctx->wf_slots;
     if (want_slots < 256)
       want_slots = 256;
     if (!ctx->wf_h_ctrl)
       HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, RT_WF_CTRL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    if (!ctx->wf_state.ptr || ctx->wf.slots < want_slots || ctx->wf_tile_slots < tile_slots) {
+    if (!ctx->wf_state.ptr || ctx->wf_capacity < want_slots || ctx->wf_tile_slots < tile_slots) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;
-      const uint32_t sl = (uint32_t)(want_slots > ctx->wf.slots ? want_slots : ctx->wf.slots);
+      const uint32_t sl = (uint32_t)(want_slots > ctx->wf_capacity ? want_slots : ctx->wf_capacity);
       HIP_TRY(ctx->wf_state.reserve(rt_wf_state_bytes(sl, ts)));
       rt_wf_carve(ctx->wf_state.ptr, sl, ts, ctx->wf);
       ctx->wf_tile_slots = ts;
+      ctx->wf_capacity = sl;
     }
+    ctx->wf.slots = (uint32_t)want_slots; // this launch's share of the allocation
     if (ctx->wf_geom_dirty || !ctx->wf_geom.ptr) {
       // the trace kernel's cooperative fetch addresses pair records and triangles as 32-bit offsets from one base
       const size_t pair_bytes = ((size_t)ctx->pair_count * sizeof(rt_dev_pair) + 255) & ~(size_t)255;
