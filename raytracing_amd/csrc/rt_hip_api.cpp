@@ -612,10 +612,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // Cornell box at 1 sample and depth 3 per frame — where every lane runs the same few steps and the plain
   // one-lane-per-pixel kernel is 1.3x faster (0.40 vs 0.53 ms at 1280x720).  All kernels give the same bits.
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
-  // ... and for the keyed PCG RNG the wavefront pipeline (kernel 9) where it measured faster (tools/bench_wf.py, C3
-  // scene): launches of at least 1.2e8 paths (1920x1080 from 64 spp on) on images of up to 2^22 pixels (at 256 spp: 4.2 against 3.65
-  // Grays/s); with fewer paths its rounds are too short, and on larger images the megakernel's waves, which stay on
-  // their 8x8 tile, are the more coherent (3840x2160: 4.6 against 4.3 Grays/s).
+  // ... and for the keyed PCG RNG the wavefront pipeline (kernel 9) where it can be faster (tools/bench_wf.py, C3 scene,
+  // 1080p, kernel 8 / kernel 9 in Grays/s: 4 spp 2.1 / 1.3, 16 spp 3.4 / 2.8, 36 spp 3.6 / 3.6, 64 spp 3.6 / 4.0,
+  // 256 spp 3.65 / 4.6; 3840x2160 at 64 spp 4.55 / 4.6): launches of at least 7e7 paths; with fewer its rounds are too
+  // short to pay for their tails and host round trips.
   // Which of the two wins depends on the scene, not only on the launch shape — closed Cornell box (every path runs to
   // full depth, short traversals): kernel 8 9.2 against 6.6 Grays/s; teapot under the sky 6.0 against 8.3; 2025
   // instances 3.2 against 4.05 (tools/bench_configs.py, 1080p) — so an eligible shape is MEASURED: its first launch
@@ -628,8 +628,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
-    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 120000000ull &&
-             (uint64_t)pc.image_width * pc.image_height <= (1ull << 22)) {
+    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 70000000ull) {
       const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
                                pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
       if (memcmp(key, ctx->tune.key, sizeof key) != 0) {
