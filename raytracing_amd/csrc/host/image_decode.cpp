@@ -8,8 +8,9 @@
 //     as stb_image does it: grey -> (g,g,g,255), grey+alpha -> (g,g,g,a), RGB -> (r,g,b,255); grey of depth 1/2/4 is
 //     scaled by 255/(2^depth-1); 16-bit samples keep their high byte; a tRNS colour key gives alpha 0.
 //   * binary PNM (P5 / P6), 8 or 16 bit.
-// JPEG (lossy: the result depends on stb_image's own IDCT and upsampling arithmetic) is not decoded; such files are
-// reported as unsupported, never approximated.
+// JPEG is lossy — the pixels depend on the decoder's IDCT, upsampling and colour arithmetic — and lives in
+// image_jpeg.cpp, which restates stb_image's published integer arithmetic for those stages (baseline / extended
+// sequential; progressive files are refused).
 #include "image_decode.h"
 
 #include <stdio.h>
@@ -488,11 +489,10 @@ bool decode_image_rgba8(const std::vector<uint8_t> &file, Image &out, std::strin
     return decode_png(file, out, err);
   if (file.size() >= 3 && file[0] == 'P' && (file[1] == '5' || file[1] == '6'))
     return decode_pnm(file, out, err);
-  if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8 && file[2] == 0xFF) {
-    err = "JPEG images are not supported (lossy: the reference's pixels depend on stb_image's own arithmetic)";
-    return false;
+  if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8 && file[2] == 0xFF) { // image_jpeg.cpp
+    return decode_jpeg(file, out, err);
   }
-  err = "unsupported image format (PNG and binary PNM are decoded)";
+  err = "unsupported image format (PNG, baseline JPEG and binary PNM are decoded)";
   return false;
 }
 

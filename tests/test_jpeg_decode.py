@@ -1,0 +1,138 @@
+"""Baseline JPEG decoding (raytracing_amd/csrc/host/image_jpeg.cpp) for add_lambert_material(path) and glTF images.
+
+The reference's decoder is stb_image, which cannot be built or run here, so PARITY IS UNPINNED: the
+decoder restates stb_image's published integer arithmetic, and these tests check it against libjpeg (through Pillow)
+within the few grey levels by which two conforming decoders differ (different IDCT constants, rounding of the
+upsampling filter and of the colour conversion), exactly where the arithmetic leaves no freedom, and on the error
+paths.  Files are written by Pillow's encoder."""
+import io
+
+import numpy as np
+import pytest
+
+from raytracing_amd import renderer as R
+from raytracing_amd import _types as T
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def _picture(w, h, seed):
+    """Smooth colour gradients plus a little texture: what a JPEG is made for (pure noise would only test clamping)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([128 + 100 * np.sin(x / 7.0 + seed) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 13.0) + 20 * np.sin(y / 3.0),
+                    40 + 200 * (x + y) / (w + h)], -1)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _jpeg_bytes(arr, **kw):
+    mode = "L" if arr.ndim == 2 else "RGB"
+    buf = io.BytesIO()
+    PIL.fromarray(arr, mode).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _decode(tmp_path, data, name="t.jpg"):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return R.decode_image(str(p))
+
+
+def _pillow(data):
+    return np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 23), (1, 1), (17, 8), (8, 33)])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])          # 4:4:4, 4:2:2, 4:2:0
+def test_colour_jpeg_matches_libjpeg_within_decoder_tolerance(tmp_path, size, subsampling):
+    w, h = size
+    data = _jpeg_bytes(_picture(w, h, 3 + subsampling), quality=90, subsampling=subsampling)
+    got = _decode(tmp_path, data)
+    want = _pillow(data)
+    assert got.shape == (h, w, 4) and (got[..., 3] == 255).all()
+    diff = np.abs(got[..., :3].astype(int) - want.astype(int))
+    if subsampling == 1 and w > 2:
+        # stb_image's 2x1 upsampling weights the second-to-last output column 3:1 towards the sample BEFORE the last one
+        # (stb_image.h:3494, `input[w-2]*3 + input[w-1]`), where the centred filter and libjpeg weight the last one:
+        # the decoder follows stb_image, so that one column is compared loosely
+        assert diff[:, 2 * ((w + 1) // 2) - 2].max() <= 40
+        diff = np.delete(diff, 2 * ((w + 1) // 2) - 2, axis=1)
+    assert diff.max() <= 4 and diff.mean() < 0.8, (diff.max(), diff.mean())
+
+
+@pytest.mark.parametrize("kw", [dict(quality=30), dict(quality=100), dict(quality=85, optimize=True),
+                                dict(quality=75, restart_marker_blocks=3), dict(quality=75, subsampling=2, restart_marker_rows=1)])
+def test_quality_huffman_optimisation_and_restart_intervals(tmp_path, kw):
+    arr = _picture(80, 56, 9)
+    try:
+        data = _jpeg_bytes(arr, **kw)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    if "restart_marker_blocks" in kw or "restart_marker_rows" in kw:
+        if b"\xff\xdd" not in data:
+            pytest.skip("this Pillow ignores the restart options")
+    got = _decode(tmp_path, data)
+    diff = np.abs(got[..., :3].astype(int) - _pillow(data).astype(int))
+    assert diff.max() <= 4 and diff.mean() < 0.8, (kw, diff.max(), diff.mean())
+
+
+def test_grey_jpeg_and_flat_blocks_are_exact(tmp_path):
+    grey = _picture(40, 24, 5)[..., 1]
+    data = _jpeg_bytes(grey, quality=92)
+    got = _decode(tmp_path, data)
+    want = np.asarray(PIL.open(io.BytesIO(data)).convert("L"))
+    assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 1], got[..., 2]) and (got[..., 3] == 255).all()
+    assert np.abs(got[..., 0].astype(int) - want.astype(int)).max() <= 2
+    # a constant image has DC-only blocks: value = clamp(((dc * q * 4) * 4096 + 65536 + (128 << 17)) >> 17), which
+    # every decoder with a correctly scaled IDCT reproduces exactly — and at quality 100 (q = 1) that is the input
+    for level in (0, 1, 77, 128, 200, 255):
+        flat = np.full((16, 24), level, np.uint8)
+        data = _jpeg_bytes(flat, quality=100)
+        got = _decode(tmp_path, data)
+        assert (got[..., :3] == level).all(), level
+        assert np.array_equal(got[..., 0], np.asarray(PIL.open(io.BytesIO(data)).convert("L")))
+
+
+def test_unsupported_and_corrupt_jpegs_are_reported(tmp_path):
+    arr = _picture(32, 32, 1)
+    good = _jpeg_bytes(arr, quality=80)
+    with pytest.raises(R.RendererError, match="progressive"):
+        _decode(tmp_path, _jpeg_bytes(arr, quality=80, progressive=True), "p.jpg")
+    with pytest.raises(R.RendererError):
+        _decode(tmp_path, good[:len(good) // 3], "cut.jpg")          # ends inside a table or the scan header
+    with pytest.raises(R.RendererError):
+        _decode(tmp_path, b"\xff\xd8\xff\xe0" + b"\0" * 64, "empty.jpg")
+    cmyk = io.BytesIO()
+    PIL.fromarray(np.zeros((8, 8, 4), np.uint8), "CMYK").save(cmyk, "JPEG")
+    with pytest.raises(R.RendererError, match="4-component"):
+        _decode(tmp_path, cmyk.getvalue(), "cmyk.jpg")
+    # a scan cut short decodes what is there (missing data reads as zero bits) or reports — it must not crash
+    sos = good.index(b"\xff\xda")
+    try:
+        _decode(tmp_path, good[: sos + 40], "short_scan.jpg")
+    except R.RendererError:
+        pass
+    # flipped bytes inside the entropy-coded data: any outcome but a crash
+    rng = np.random.default_rng(4)
+    for k in range(40):
+        bad = bytearray(good)
+        for _ in range(3):
+            bad[int(rng.integers(sos, len(bad) - 2))] = int(rng.integers(0, 256))
+        try:
+            _decode(tmp_path, bytes(bad), "flip.jpg")
+        except R.RendererError:
+            pass
+
+
+def test_jpeg_texture_reaches_the_material_table(tmp_path):
+    data = _jpeg_bytes(_picture(16, 8, 2), quality=95, subsampling=0)
+    (tmp_path / "albedo.jpg").write_bytes(data)
+    r = R.Renderer(8, 8, device=None)
+    h = r.add_lambert_image(str(tmp_path / "albedo.jpg"))
+    assert h.type == T.MATERIAL_LAMBERT
+    sa = r.scene_arrays()
+    off, tw, th = (int(v) for v in list(sa.textures[int(sa.lamberts[h.index])])[:3])
+    assert (tw, th) == (16, 8)
+    texels = np.asarray(sa.texels[off: off + 16 * 8 * 4]).reshape(8, 16, 4)
+    assert np.array_equal(texels, _decode(tmp_path, data, "again.jpg"))

@@ -35,6 +35,27 @@ def flips(raw, name, count, lo, hi, first=0, per=3):
         (out / name.format(k)).write_bytes(bytes(b))
 
 
+# JPEG: valid files over subsampling modes and restart intervals, truncations, flips in headers and in the scan
+try:
+    import io
+    from PIL import Image as _PIL
+    from tests.test_jpeg_decode import _picture
+    for k, kw in enumerate([dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, optimize=True),
+                            dict(subsampling=2, restart_marker_blocks=2)]):
+        buf = io.BytesIO()
+        try:
+            _PIL.fromarray(_picture(45, 31, k)).save(buf, "JPEG", quality=80, **kw)
+        except TypeError:
+            continue
+        raw = buf.getvalue()
+        (out / f"ok_{k}.jpg").write_bytes(raw)
+        for t in range(1, 6):
+            (out / f"cut_{k}_{t}.jpg").write_bytes(raw[: len(raw) * t // 6])
+        flips(raw, f"flip_{k}_{{}}.jpg", 24, 0, 256, first=2, per=2)
+except ImportError:
+    pass
+
+
 flips(open(G._author(out, glb=False, embed=True)[0], "rb").read(), "fuzz_{}.gltf", 40, 32, 127)
 flips(open(G._author(out, glb=True, embed=True)[0], "rb").read(), "fuzz_{}.glb", 40, 0, 256, first=12)
 flips(open(os.path.join(ROOT, "assets", "teapot.obj"), "rb").read()[:20000], "fuzz_{}.obj", 40, 32, 127, per=20)

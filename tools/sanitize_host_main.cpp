@@ -35,6 +35,9 @@ int main(int argc, char **argv) {
       } else {
         ++bad;
       }
+    } else if (p.size() > 4 && p.substr(p.size() - 4) == ".jpg") {
+      rta::Image img;
+      (rta::load_image_rgba8(p, img, err) ? ok : bad)++;
     } else if (p.size() > 4 && p.substr(p.size() - 4) == ".obj") {
       rta::ObjModel m;
       (rta::load_obj(p, m, err) ? ok : bad)++;
