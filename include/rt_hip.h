@@ -106,7 +106,7 @@ int rt_reset_stats(rt_ctx *ctx);
  * blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
  * rt_launch_render).  All kernels give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new
  * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
- * depth 3 per launch (the reference's live configuration), and except RT_RNG_PCG launches of at least 7e7 paths (1920x1080 from 36 samples per pixel on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
+ * depth 3 per launch (the reference's live configuration), and except RT_RNG_PCG launches of at least 2e7 paths (1920x1080 from 10 samples per pixel on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
  * launch of a (scene, launch shape) runs kernel 9, the second kernel 8, both timed (rt_render waits for them), and
  * the following ones the faster of the two.  rt_stats.last_kernel reports the choice.  The kernels
  * that round 1 measured and dropped (numbers 1-7, 10) are in experiments/r01_variants/, outside the library. */

@@ -3,6 +3,7 @@
 // rt_create fails.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <math.h>
 #include <cmath>
@@ -614,8 +615,10 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   // dev.cache_pairs = node pairs reachable from the TLAS root (counted up to RT_CACHE_PAIRS at upload).
   // ... and for the keyed PCG RNG the wavefront pipeline (kernel 9) where it can be faster (tools/bench_wf.py, C3 scene,
   // 1080p, kernel 8 / kernel 9 in Grays/s: 4 spp 2.1 / 1.3, 16 spp 3.4 / 2.8, 36 spp 3.6 / 3.6, 64 spp 3.6 / 4.0,
-  // 256 spp 3.65 / 4.6; 3840x2160 at 64 spp 4.55 / 4.6): launches of at least 7e7 paths; with fewer its rounds are too
-  // short to pay for their tails and host round trips.
+  // 256 spp 3.65 / 4.6; 3840x2160 at 64 spp 4.55 / 4.6): launches of at least 2e7 paths.  The threshold is low because
+  // of the multi-GPU shards (tools/bench_shard.py): a rank's eighth of a 1080p frame at 256 spp is 6.6e7 paths on only
+  // 2.6e5 pixels — about one pixel per lane of kernel 8, whose lanes run a pixel's samples one after the other, so it
+  // takes as long as the longest pixel (186 ms, against 43 ms for kernel 9, which spreads the samples).
   // Which of the two wins depends on the scene, not only on the launch shape — closed Cornell box (every path runs to
   // full depth, short traversals): kernel 8 9.2 against 6.6 Grays/s; teapot under the sky 6.0 against 8.3; 2025
   // instances 3.2 against 4.05 (tools/bench_configs.py, 1080p) — so an eligible shape is MEASURED: its first launch
@@ -628,7 +631,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
-    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 70000000ull) {
+    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 20000000ull) {
       const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
                                pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
       if (memcmp(key, ctx->tune.key, sizeof key) != 0) {
@@ -662,7 +665,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
     if (chunk_paths < tile_slots)
       chunk_paths = tile_slots;
-    uint64_t want_slots = (chunk_paths / 8 + 255) / 256 * 256;
+    uint64_t want_slots = (chunk_paths / 8 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
     if (want_slots < (1u << 20))
       want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
     if (want_slots > ctx->wf_slots)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU run renders per step (interleaved 8-row groups, row_group_stride = N) on ONE GPU:
+kernel 8 against kernel 9 on the bench scene, 1920x1080, 256 spp, keyed PCG."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
+from raytracing_amd import _ffi, _types as T, renderer as R
+r = R.Renderer(1920, 1080, device=0)
+cam, n = bench.build_dragon_scene(R, r)
+r.set_option(R.OPT_SAMPLES_PER_PIXEL, 256); r.set_option(R.OPT_MAX_DEPTH, 8); r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
+for stride in (8, 4, 2):
+    r.set_option(R.OPT_ROW_BEGIN, 0); r.set_option(R.OPT_ROW_END, 1080); r.set_option(R.OPT_ROW_GROUP_STRIDE, stride)
+    for variant in (8, 9):
+        r.set_option(R.OPT_KERNEL_VARIANT, variant)
+        best = None
+        for rep in range(3):
+            _ffi._check(L.rt_reset_stats(ctx)); t0 = time.perf_counter(); r.render(cam); r.wait(); dt = time.perf_counter() - t0
+            st = _ffi.Stats(); _ffi._check(L.rt_get_stats(ctx, C.byref(st)))
+            if rep and (best is None or dt < best[0]): best = (dt, st.rays_traced)
+        print(f"stride {stride} kernel {variant}: {best[0]*1e3:.2f} ms {best[1]/best[0]/1e6:.0f} Mrays/s", flush=True)
