@@ -206,7 +206,9 @@ __global__ void __launch_bounds__(RT_BLOCK)
 // per atomic from striped queue heads.
 // ---------------------------------------------------------------------------
 enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
-#define WF_GRAB 512u
+#define WF_GRAB 512u // measured 64 ... 4096 on full frames and on multi-GPU shards (tools/bench_shard.py): 512 is best on all
+                     // (256: -2 ... -5 %, 64-128: -40 % on a shard, 1024: -0 ... -12 %); asking for the next share in advance
+                     // (asynchronous atomic) made it no faster: a wave then holds two shares, which lengthens the tail
 
 //
 // COOP: quad-cooperative record fetch.  A lane that gathers its own 64-byte record with four 16-byte loads costs the
