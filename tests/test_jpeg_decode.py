@@ -136,3 +136,27 @@ def test_jpeg_texture_reaches_the_material_table(tmp_path):
     assert (tw, th) == (16, 8)
     texels = np.asarray(sa.texels[off: off + 16 * 8 * 4]).reshape(8, 16, 4)
     assert np.array_equal(texels, _decode(tmp_path, data, "again.jpg"))
+
+
+def test_gltf_asset_with_a_jpeg_texture(tmp_path):
+    """The external image of the glTF test asset swapped for a JPEG (mimeType image/jpeg, as exporters write it): the
+    texture that reaches the scene arrays is what the decoder returns for that file."""
+    import json
+    from . import test_gltf_import as G
+    path, desc = G._author(tmp_path, glb=False, embed=False)
+    doc = json.loads(open(path).read())
+    ext = [i for i, im in enumerate(doc["images"]) if "uri" in im and not im["uri"].startswith("data:")]
+    assert ext
+    data = _jpeg_bytes(_picture(24, 16, 6), quality=88, subsampling=2)
+    (tmp_path / "albedo.jpg").write_bytes(data)
+    doc["images"][ext[0]] = {"uri": "albedo.jpg", "mimeType": "image/jpeg"}
+    (tmp_path / "with_jpeg.gltf").write_text(json.dumps(doc))
+    r = R.Renderer(8, 8, device=None)
+    r.import_gltf(str(tmp_path / "with_jpeg.gltf"))
+    sa = r.scene_arrays()
+    want = _decode(tmp_path, data, "again.jpg")
+    found = False
+    for off, tw, th, _ in (tuple(int(v) for v in t) for t in sa.textures):
+        if (tw, th) == (24, 16):
+            found = found or np.array_equal(np.asarray(sa.texels[off: off + 24 * 16 * 4]).reshape(16, 24, 4), want)
+    assert found
