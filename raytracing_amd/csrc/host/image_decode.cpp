@@ -10,7 +10,7 @@
 //   * binary PNM (P5 / P6), 8 or 16 bit.
 // JPEG is lossy — the pixels depend on the decoder's IDCT, upsampling and colour arithmetic — and lives in
 // image_jpeg.cpp, which restates stb_image's published integer arithmetic for those stages (baseline / extended
-// sequential; progressive files are refused).
+// sequential and progressive).
 #include "image_decode.h"
 
 #include <stdio.h>
@@ -492,7 +492,7 @@ bool decode_image_rgba8(const std::vector<uint8_t> &file, Image &out, std::strin
   if (file.size() >= 3 && file[0] == 0xFF && file[1] == 0xD8 && file[2] == 0xFF) { // image_jpeg.cpp
     return decode_jpeg(file, out, err);
   }
-  err = "unsupported image format (PNG, baseline JPEG and binary PNM are decoded)";
+  err = "unsupported image format (PNG, JPEG and binary PNM are decoded)";
   return false;
 }
 

@@ -1,5 +1,5 @@
 // image_decode.h — image files to RGBA8 for Renderer::add_lambert_material(path) (src/Renderer.cpp:705-716,
-// which calls stbi_load(path, &w, &h, &comp, 4)).  PNG, binary PNM (image_decode.cpp) and baseline JPEG (image_jpeg.cpp).
+// which calls stbi_load(path, &w, &h, &comp, 4)).  PNG, binary PNM (image_decode.cpp) and JPEG (image_jpeg.cpp).
 #ifndef RTA_IMAGE_DECODE_H
 #define RTA_IMAGE_DECODE_H
 

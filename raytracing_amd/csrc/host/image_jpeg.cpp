@@ -1,4 +1,4 @@
-// image_jpeg.cpp — baseline / extended-sequential Huffman JPEG (ITU-T T.81, JFIF) to RGBA8 for
+// image_jpeg.cpp — baseline / extended-sequential / progressive Huffman JPEG (ITU-T T.81, JFIF) to RGBA8 for
 // Renderer::add_lambert_material(path) (src/Renderer.cpp:705-716: stbi_load(path, &w, &h, &comp, 4)) and glTF images
 // (SceneGraph.cpp:42-166).
 //
@@ -11,10 +11,10 @@
 // masked green term (:3657-3683).  PARITY UNPINNED: no run of stb_image is available to compare with; the tests check
 // against libjpeg (Pillow) within the few levels two conforming decoders differ by, and exactly where the arithmetic
 // leaves no freedom (flat blocks).
-// Decoded: SOF0 / SOF1, 8-bit samples, 1 component (grey -> g,g,g,255) or 3 (YCbCr, or RGB when an Adobe APP14 marker
+// Decoded: SOF0 / SOF1 / SOF2 (baseline, extended sequential, progressive), 8-bit samples, 1 component (grey -> g,g,g,255) or 3 (YCbCr, or RGB when an Adobe APP14 marker
 // or the component ids 'R','G','B' say so), interleaved and non-interleaved scans, restart intervals, 8- and 16-bit
-// quantisation tables.  Refused with a message: progressive (SOF2), lossless / arithmetic-coded frames, 12-bit
-// samples, 4 components (CMYK / YCCK).
+// quantisation tables.  Refused with a message: lossless / arithmetic-coded frames, 12-bit samples, 4 components
+// (CMYK / YCCK).
 #include "image_decode.h"
 
 #include <string.h>
@@ -54,6 +54,7 @@ struct Component {
   uint32_t x = 0, y = 0;   // samples that carry image data
   uint32_t w2 = 0, h2 = 0; // allocated plane (whole MCUs)
   std::vector<uint8_t> plane;
+  std::vector<short> coef; // progressive frames: every block's 64 coefficients in natural order, summed over the scans
 };
 
 struct EntropyReader { // the scan's bit stream: 0xFF00 is a stuffed 0xFF, any other marker ends the data (zeros follow)
@@ -238,7 +239,8 @@ struct Decoder {
   uint32_t width = 0, height = 0, mcu_x = 0, mcu_y = 0;
   int hmax = 1, vmax = 1;
   uint32_t restart_interval = 0;
-  bool have_frame = false, jfif = false;
+  bool have_frame = false, jfif = false, progressive = false;
+  uint32_t eob_run = 0; // progressive AC scans: blocks still covered by the last end-of-band run (T.81 G.1.2.2)
   int adobe_transform = -1;
   bool rgb_ids = false;
 
@@ -287,7 +289,8 @@ struct Decoder {
     }
     return true;
   }
-  bool read_sof(size_t p, size_t end) {
+  bool read_sof(size_t p, size_t end, bool prog) {
+    progressive = prog;
     if (have_frame)
       return fail("more than one frame");
     if (end - p < 6)
@@ -331,6 +334,8 @@ struct Decoder {
       c.x = (width * c.h + hmax - 1) / hmax, c.y = (height * c.v + vmax - 1) / vmax;
       c.w2 = mcu_x * c.h * 8, c.h2 = mcu_y * c.v * 8;
       c.plane.assign((size_t)c.w2 * c.h2, 0);
+      if (progressive)
+        c.coef.assign((size_t)c.w2 * c.h2, 0); // (w2 / 8) * (h2 / 8) blocks of 64
     }
     have_frame = true;
     return true;
@@ -367,6 +372,105 @@ struct Decoder {
     return true;
   }
 
+  // Progressive frames (T.81 Annex G; the decoding procedures are fixed by the standard, stb_image.h:2265-2413 follows
+  // them): a scan carries either the DC coefficients (Ss = 0) or one band Ss..Se of the AC coefficients of ONE component,
+  // as a first pass (Ah = 0: values shifted left by Al) or as a refinement of one more bit (Ah > 0).
+  bool prog_dc(EntropyReader &br, Component &c, short *d, int ah, int al) {
+    if (ah == 0) {
+      const int t = decode_symbol(br, dc[c.td]);
+      if (t < 0 || t > 15)
+        return fail("bad Huffman code");
+      c.dc_pred += t ? extend(br.receive(t), t) : 0;
+      d[0] = (short)(c.dc_pred * (1 << al));
+    } else if (br.bit()) {
+      d[0] = (short)(d[0] + (1 << al));
+    }
+    return true;
+  }
+  static void refine(EntropyReader &br, short *p, short bit) { // one correction bit for a coefficient already nonzero
+    if (br.bit() && (*p & bit) == 0)
+      *p = (short)(*p > 0 ? *p + bit : *p - bit);
+  }
+  bool prog_ac(EntropyReader &br, Component &c, short *d, int ss, int se, int ah, int al) {
+    const HuffTable &t = ac[c.ta];
+    if (ah == 0) {
+      if (eob_run) {
+        --eob_run;
+        return true;
+      }
+      for (int k = ss; k <= se;) {
+        const int rs = decode_symbol(br, t);
+        if (rs < 0)
+          return fail("bad Huffman code");
+        const int s = rs & 15, r = rs >> 4;
+        if (s == 0) {
+          if (r < 15) { // EOBn: this block and 2^r + bits - 1 more end here
+            eob_run = (1u << r) + (r ? (uint32_t)br.receive(r) : 0u) - 1u;
+            break;
+          }
+          k += 16;
+        } else {
+          k += r;
+          if (k > 63)
+            return fail("coefficient index past the block");
+          d[kZigzag[k++]] = (short)(extend(br.receive(s), s) * (1 << al));
+        }
+      }
+      return true;
+    }
+    const short bit = (short)(1 << al);
+    if (eob_run) {
+      --eob_run;
+      for (int k = ss; k <= se; ++k)
+        if (d[kZigzag[k]] != 0)
+          refine(br, &d[kZigzag[k]], bit);
+      return true;
+    }
+    int k = ss;
+    do {
+      const int rs = decode_symbol(br, t);
+      if (rs < 0)
+        return fail("bad Huffman code");
+      int s = rs & 15, r = rs >> 4;
+      if (s == 0) {
+        if (r < 15) {
+          eob_run = (1u << r) - 1u + (r ? (uint32_t)br.receive(r) : 0u);
+          r = 64; // the rest of the band only takes correction bits
+        }
+      } else {
+        if (s != 1)
+          return fail("bad Huffman code");
+        s = br.bit() ? bit : -bit; // the new coefficient's value: +-2^Al
+      }
+      while (k <= se) { // skip r zero coefficients (correcting the nonzero ones on the way), then place s
+        short *p = &d[kZigzag[k++]];
+        if (*p != 0) {
+          refine(br, p, bit);
+        } else {
+          if (r == 0) {
+            *p = (short)s;
+            break;
+          }
+          --r;
+        }
+      }
+    } while (k <= se);
+    return true;
+  }
+  void finish_progressive() { // dequantise and transform every block (stb_image.h:3080-3097)
+    for (int n = 0; n < ncomp; ++n) {
+      Component &c = comp[n];
+      const uint32_t bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3, cw = c.w2 / 8;
+      for (uint32_t j = 0; j < bh; ++j)
+        for (uint32_t i = 0; i < bw; ++i) {
+          short *d = &c.coef[64 * ((size_t)j * cw + i)];
+          for (int k = 0; k < 64; ++k)
+            d[k] = (short)(d[k] * quant[c.tq][k]);
+          idct_block(&c.plane[(size_t)j * 8 * c.w2 + (size_t)i * 8], c.w2, d);
+        }
+    }
+  }
+
   bool read_scan(size_t p, size_t end) {
     if (!have_frame)
       return fail("scan before the frame header");
@@ -385,14 +489,23 @@ struct Decoder {
       if (which < 0)
         return fail("scan names an unknown component");
       comp[which].td = tables >> 4, comp[which].ta = tables & 15;
-      if (comp[which].td > 3 || comp[which].ta > 3 || !dc[comp[which].td].defined || !ac[comp[which].ta].defined ||
-          !quant_defined[comp[which].tq])
+      if (comp[which].td > 3 || comp[which].ta > 3 || !quant_defined[comp[which].tq])
         return fail("scan uses an undefined table");
       order[i] = which;
     }
     const size_t q = p + 1 + 2 * (size_t)ns;
-    if (f[q] != 0 || f[q + 1] != 63 || f[q + 2] != 0)
+    const int ss = f[q], se = f[q + 1], ah = f[q + 2] >> 4, al = f[q + 2] & 15;
+    if (!progressive && (ss != 0 || se != 63 || ah != 0 || al != 0))
       return fail("spectral selection / successive approximation in a sequential frame");
+    if (progressive && (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13 || (ss == 0 && se != 0) || (ss != 0 && ns != 1)))
+      return fail("bad progressive scan parameters");
+    for (int i = 0; i < ns; ++i) { // only the tables the scan reads need to exist
+      const Component &c = comp[order[i]];
+      const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss != 0;
+      if ((need_dc && !dc[c.td].defined) || (need_ac && !ac[c.ta].defined))
+        return fail("scan uses an undefined table");
+    }
+    eob_run = 0;
     EntropyReader br{&f[0] + end, &f[0] + f.size()};
     for (int k = 0; k < ncomp; ++k)
       comp[k].dc_pred = 0;
@@ -413,15 +526,22 @@ struct Decoder {
       br.reset();
       for (int k = 0; k < ncomp; ++k)
         comp[k].dc_pred = 0;
+      eob_run = 0;
       todo = restart_interval;
       return true;
+    };
+    auto block = [&](Component &c, size_t bi, size_t bj) -> bool { // block (bi, bj) of the component's plane
+      if (!progressive)
+        return decode_block(br, c, &c.plane[bj * 8 * c.w2 + bi * 8]);
+      short *d = &c.coef[64 * (bj * (c.w2 / 8) + bi)];
+      return ss == 0 ? prog_dc(br, c, d, ah, al) : prog_ac(br, c, d, ss, se, ah, al);
     };
     if (ns == 1) { // non-interleaved: the component's own blocks, row by row
       Component &c = comp[order[0]];
       const uint32_t bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
       for (uint32_t j = 0; j < bh; ++j)
         for (uint32_t i = 0; i < bw; ++i) {
-          if (!decode_block(br, c, &c.plane[(size_t)j * 8 * c.w2 + (size_t)i * 8]))
+          if (!block(c, i, j))
             return false;
           restart_if_due();
         }
@@ -432,8 +552,7 @@ struct Decoder {
             Component &c = comp[order[k]];
             for (int y = 0; y < c.v; ++y)
               for (int x = 0; x < c.h; ++x) {
-                const size_t bx = ((size_t)i * c.h + x) * 8, by = ((size_t)j * c.v + y) * 8;
-                if (!decode_block(br, c, &c.plane[by * c.w2 + bx]))
+                if (!block(c, (size_t)i * c.h + x, (size_t)j * c.v + y))
                   return false;
               }
           }
@@ -469,11 +588,9 @@ struct Decoder {
       } else if (m == 0xC4) {
         if (!read_dht(p, end))
           return false;
-      } else if (m == 0xC0 || m == 0xC1) {
-        if (!read_sof(p, end))
+      } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+        if (!read_sof(p, end, m == 0xC2))
           return false;
-      } else if (m == 0xC2) {
-        return fail("progressive JPEG files are not decoded (baseline and extended sequential are)");
       } else if (m >= 0xC3 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
         return fail("lossless, differential and arithmetic-coded frames are not decoded");
       } else if (m == 0xCC) {
@@ -496,6 +613,8 @@ struct Decoder {
     }
     if (!have_frame || !saw_scan)
       return fail("no image data");
+    if (progressive)
+      finish_progressive();
     return true;
   }
 

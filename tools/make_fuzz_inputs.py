@@ -41,7 +41,8 @@ try:
     from PIL import Image as _PIL
     from tests.test_jpeg_decode import _picture
     for k, kw in enumerate([dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, optimize=True),
-                            dict(subsampling=2, restart_marker_blocks=2)]):
+                            dict(subsampling=2, restart_marker_blocks=2), dict(subsampling=2, progressive=True),
+                            dict(subsampling=0, progressive=True, optimize=True)]):
         buf = io.BytesIO()
         try:
             _PIL.fromarray(_picture(45, 31, k)).save(buf, "JPEG", quality=80, **kw)
