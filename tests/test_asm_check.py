@@ -1,0 +1,61 @@
+"""tools/check_v8_asm.py — the build-time guard of the uncounted inline-assembly loads — on synthetic
+assembly: it must pass the shape the compiler produces today and fail on the two hazards it exists for."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_v8_asm", os.path.join(ROOT, "tools", "check_v8_asm.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+GOOD = """
+_Z11k_render_v8ILi0ELi4ELi256ELi24EEvv:
+\ts_mov_b64 s[10:11], exec
+\t; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)
+\tglobal_load_dwordx4 v[16:19], v[66:67], off
+\tglobal_load_dwordx4 v[12:15], v[66:67], off offset:16
+\tglobal_load_dwordx4 v[8:11], v[66:67], off offset:32
+\tglobal_load_dwordx2 v[44:45], v[66:67], off offset:48
+\t; RT_V8_LOADS_END
+\tv_mov_b32_e32 v63, v7
+\ts_cbranch_execz .LBB0_2
+\ts_waitcnt vmcnt(0) ; RT_V8_WAIT_TRI
+\tv_mul_f32_e32 v63, v34, v10
+.LBB0_2:
+\ts_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR
+\tv_pk_add_f32 v[16:17], v[16:17], v[30:31]
+\ts_endpgm
+  - .name:           _Z11k_render_v8ILi0ELi4ELi256ELi24EEvv
+    .sgpr_count:     106
+    .sgpr_spill_count: 2
+    .vgpr_count:     108
+    .vgpr_spill_count: 0
+"""
+
+
+def _run(tmp_path, text):
+    p = tmp_path / "k.s"
+    p.write_text(text)
+    return chk.check(str(p))
+
+
+def test_todays_shape_passes(tmp_path):
+    groups, errors = _run(tmp_path, GOOD)
+    assert groups == 1 and errors == []
+
+
+def test_a_copy_of_an_in_flight_register_is_caught(tmp_path):
+    bad = GOOD.replace("\tv_mov_b32_e32 v63, v7\n", "\tv_mov_b32_e32 v63, v12\n")     # reads v12 before any wait
+    groups, errors = _run(tmp_path, bad)
+    assert groups == 1 and len(errors) == 1 and "in-flight" in errors[0]
+
+
+def test_vector_spills_are_caught(tmp_path):
+    bad = GOOD.replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 3")
+    groups, errors = _run(tmp_path, bad)
+    assert any("vector register spills" in e for e in errors)
+
+
+def test_a_missing_marker_is_caught(tmp_path):
+    groups, errors = _run(tmp_path, "_Z11k_render_v8ILi0EEvv:\n\ts_endpgm\n")
+    assert groups == 0 and errors
