@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
@@ -85,6 +85,8 @@ def lib():
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
+    L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32]
+    L.rt_debug_wavefront_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -208,6 +210,15 @@ class HipContext:
 
     def set_wavefront_budget(self, paths_in_flight, result_bytes):
         _check(lib().rt_set_wavefront_budget(self._h, paths_in_flight, result_bytes))
+
+    def wavefront_tuning(self, suspend_lanes=0xFFFFFFFF, list_percent=0xFFFFFFFF, share=0xFFFFFFFF):
+        _check(lib().rt_debug_wavefront_tuning(self._h, suspend_lanes, list_percent, share))
+
+    def wavefront_counts(self):
+        """(rounds, rounds whose trace pass walked the live-slot list, rays suspended) since reset_stats."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().rt_debug_wavefront_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))

@@ -88,6 +88,8 @@ struct rt_ctx {
   uint32_t wf_capacity = 0;              // slots the state allocation holds
   uint64_t wf_sr_bytes = 10ull << 30;    // result buffer: 16 B per path of a sample chunk
   uint32_t *wf_h_ctrl = nullptr;
+  rt_wf_tuning wf_tuning;                // rt_debug_wavefront_tuning
+  rt_wf_counts wf_counts;                // since rt_reset_stats
   rt_dev_scene dev{};
   bool have_scene = false;
   // host-side remnants needed by rt_update_instances
@@ -350,11 +352,11 @@ int rt_create(int device_id, rt_ctx **out_ctx) {
   hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   ctx->stream = ctx->own_stream;
   if (e == hipSuccess)
-    e = ctx->counter.reserve(1);
+    e = ctx->counter.reserve(2); // rays traced; rays suspended (kernel 9)
   if (e == hipSuccess)
     e = ctx->queue.reserve(64);
   if (e == hipSuccess)
-    e = hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream);
+    e = hipMemsetAsync(ctx->counter.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream);
   int cus = 0;
   if (e == hipSuccess)
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
@@ -631,7 +633,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
-    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 29) && paths >= 20000000ull) {
+    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 20000000ull) {
       const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
                                pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
       if (memcmp(key, ctx->tune.key, sizeof key) != 0) {
@@ -652,8 +654,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     if (pc.rng_mode != RT_RNG_PCG)
       return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
                                       "state runs through a pixel's samples, so they cannot be traced side by side");
-    if (pc.max_depth >= (1u << 29))
-      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^29)");
+    if (pc.max_depth >= (1u << 28))
+      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^28)");
     // HBM state of the pipeline, sized for this launch shape and kept for the next one
     const uint32_t rows = rt_virtual_rows(pc);
     const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
@@ -678,8 +680,9 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;
       const uint32_t sl = (uint32_t)(want_slots > ctx->wf_capacity ? want_slots : ctx->wf_capacity);
-      HIP_TRY(ctx->wf_state.reserve(rt_wf_state_bytes(sl, ts)));
-      rt_wf_carve(ctx->wf_state.ptr, sl, ts, ctx->wf);
+      const uint32_t pool = rt_wf_pool_records(ctx->cus);
+      HIP_TRY(ctx->wf_state.reserve(rt_wf_state_bytes(sl, ts, pool)));
+      rt_wf_carve(ctx->wf_state.ptr, sl, ts, pool, ctx->wf);
       ctx->wf_tile_slots = ts;
       ctx->wf_capacity = sl;
     }
@@ -721,7 +724,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   const hipError_t le =
       wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->wf_geom_desc, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
                                              ctx->wf, ctx->wf_h_ctrl, variant | (ctx->variant_auto ? 0u : ctx->regen_idle << 8),
-                                             ctx->cus, ctx->stream) // bits 8-15: kernel 9's own knobs
+                                             ctx->wf_tuning, &ctx->wf_counts, ctx->cus, ctx->stream) // bits 8-15: kernel 9's own knobs
                 : rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
                                    effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
   if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent
@@ -854,9 +857,10 @@ int rt_reset_stats(rt_ctx *ctx) {
   int rc = drain_events(ctx);
   if (rc != RT_OK)
     return rc;
-  HIP_TRY(hipMemsetAsync(ctx->counter.ptr, 0, sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->counter.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
   ctx->total_ms = ctx->last_ms = 0.0;
   ctx->launches = 0;
+  ctx->wf_counts = rt_wf_counts{};
   return RT_OK;
 }
 
@@ -890,6 +894,29 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
   HIP_TRY(hipMemcpy(ctx->counter.ptr, &before, sizeof before, hipMemcpyHostToDevice)); // not rays
   *out_ms = ctx->last_ms;
   *out_steps = after - before;
+  return RT_OK;
+}
+
+int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_tuning: NULL context");
+  ctx->wf_tuning.suspend_lanes = suspend_lanes;
+  ctx->wf_tuning.list_percent = list_percent;
+  ctx->wf_tuning.share = share;
+  ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old settings
+  return RT_OK;
+}
+
+int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays) {
+  if (!ctx || !rounds || !list_rounds || !suspended_rays)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_counts: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  unsigned long long susp = 0;
+  HIP_TRY(hipMemcpy(&susp, ctx->counter.ptr + 1, sizeof susp, hipMemcpyDeviceToHost));
+  *rounds = ctx->wf_counts.rounds;
+  *list_rounds = ctx->wf_counts.list_rounds;
+  *suspended_rays = susp;
   return RT_OK;
 }
 

@@ -9,7 +9,7 @@
 
 // Path state between rounds, structure-of-arrays over path slots (84 B per slot in HBM; the depth word of ray_d is
 // 0xFFFFFFFF for a slot without a path), and the per-path result buffer of one sample chunk.
-#define RT_WF_CTRL_WORDS 8192u
+#define RT_WF_CTRL_WORDS 12288u
 struct rt_wf_buffers {
   float4 *ray_o;      // [slots] origin.xyz, path id within the chunk (bits)
   float4 *ray_d;      // [slots] direction.xyz, depth (bits)
@@ -21,6 +21,9 @@ struct rt_wf_buffers {
   uint32_t *block_pos; // [slots / 256] every shade workgroup's position in its share of the chunk's path ids
   float4 *partial;    // [tile slots] radiance summed over the sample chunks done so far
   float4 *sr;         // [sr_paths] sample radiance of every path of the current chunk, in path-id order
+  uint32_t *live;     // [64 stripes][list span] slots with a live path after the last shade pass (lengths in ctrl)
+  uint32_t *pool;     // [2][pool_records][64 words] traversal state of suspended rays, written in one round, read in the next
+  uint32_t pool_records;
   uint32_t slots;     // capacity: paths in flight
   uint64_t sr_paths;  // capacity of sr
 };
@@ -33,14 +36,28 @@ struct rt_wf_geom {
   uint32_t tris_off;  // byte offset of triangle 0
 };
 
-size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots);
-void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b);
+uint32_t rt_wf_pool_records(uint32_t cus);
+size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records);
+void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t pool_records, rt_wf_buffers &b);
 
-// One rt_render launch through the pipeline.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the
+// How the rounds are scheduled; 0xFFFFFFFF in a field = the measured default.
+struct rt_wf_tuning {
+  uint32_t suspend_lanes = 0xFFFFFFFFu; // a trace wave out of fresh slots gives up its rays once this many or fewer are left
+                                        // (they resume next round; 0 = never; default 32)
+  uint32_t list_percent = 0xFFFFFFFFu;  // the trace pass walks the live-slot list once fewer than this % of the slots are
+                                        // alive (0 = never; default 75)
+  uint32_t share = 0xFFFFFFFFu;         // slots a wave takes per atomic (a multiple of 64; default 256)
+};
+struct rt_wf_counts { // statistics, summed over launches
+  uint64_t rounds = 0;      // trace + shade rounds
+  uint64_t list_rounds = 0; // of these, rounds whose trace pass walked the live-slot list
+};
+
+// One rt_render launch through the pipeline.  d_counter: two words, rays traced and rays suspended.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the
 // image is complete (the host reads the list lengths back between rounds).  pc.rng_mode must be RT_RNG_PCG.
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
-                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
-                                      hipStream_t stream);
+                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, const rt_wf_tuning &tune,
+                                      rt_wf_counts *counts, uint32_t cus, hipStream_t stream);
 
 #endif

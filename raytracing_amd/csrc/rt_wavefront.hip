@@ -37,10 +37,17 @@ namespace {
 #define WF_STRIPES 64u
 #define WF_PAD 64u
 enum : uint32_t {
-  WF_HEAD = 0,                              // [WF_STRIPES * WF_PAD] next slot of each band of the slot space (k_wf_trace)
-  WF_ALIVE = WF_HEAD + WF_STRIPES * WF_PAD, // [..] live paths after the round (summed by the host)
-  WF_CTRL_WORDS = WF_ALIVE + WF_STRIPES * WF_PAD
+  // live paths after a shade pass, per stripe (summed by the host; the lengths of the live-slot list's segments).
+  // Two sets: pass p counts into set p & 1 while the trace pass before it still reads set (p - 1) & 1.  The heads sit
+  // between them so that the heads and either set are cleared with one memset.
+  WF_ALIVE0 = 0,
+  WF_HEAD = WF_ALIVE0 + WF_STRIPES * WF_PAD, // [WF_STRIPES * WF_PAD] next slot of each band of the slot space (k_wf_trace)
+  WF_USED = WF_HEAD + 32,                   // 64 bits, one per band whose slots are all handed out (a cache line of its own
+                                            // inside band 0's padding; cleared with the heads)
+  WF_ALIVE1 = WF_HEAD + WF_STRIPES * WF_PAD,
+  WF_CTRL_WORDS = WF_ALIVE1 + WF_STRIPES * WF_PAD
 };
+__host__ __device__ inline uint32_t wf_alive_set(uint32_t pass) { return (pass & 1u) ? WF_ALIVE1 : WF_ALIVE0; }
 #define WF_DEAD 0xFFFFFFFFu // depth word of a slot without a path
 // Depth word bit 30: the slot's `rad` entry holds the path's sample radiance.  Clear = the radiance is +0, +0, +0 and
 // `rad` is neither written nor read — the state of practically every path until its last bounce, since only an emitter
@@ -51,6 +58,14 @@ enum : uint32_t {
 // Depth word bit 29: the slot's `att` entry holds the path's attenuation.  Clear = a fresh path, attenuation 1, 1, 1
 // (RayTracing.slang:88): not written by the regeneration, not read by the path's first shade.
 #define WF_HAS_ATT 0x20000000u
+// Depth word bit 28: the slot's ray is SUSPENDED — a trace wave that ran out of fresh slots with only a few rays left
+// wrote their traversal state (node cursor, closest hit, stack) to the pool record whose index sits in hit_v[slot]
+// and ended; the shade pass leaves such a slot alone and the next round's trace pass resumes the ray where it stopped,
+// in a wave with full lanes.  (max_depth >= 2^28 is refused by the launcher.)
+#define WF_SUSPENDED 0x10000000u
+#define WF_SUSP_STEPS 64u
+#define WF_REC_WORDS 64u                    // pool record: 8 words of state + the stack entries, 256 B
+#define WF_REC_STACK (WF_REC_WORDS - 8u)    // deepest stack a record holds; a wave with a deeper one does not suspend
 
 struct WfChunk {
   uint32_t s0;       // first sample of the chunk
@@ -59,6 +74,7 @@ struct WfChunk {
   uint32_t total;    // path ids of the chunk: tiles * cs * 64
   uint32_t slots;    // path slots in use for this chunk
   uint32_t slot_span; // slots per band of the trace kernel's queue (a multiple of 64)
+  uint32_t list_span; // entries per stripe of the live-slot list: the slots of the shade workgroups of one stripe
 };
 
 __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const WfChunk &ch, uint32_t id, uint32_t &x,
@@ -138,7 +154,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
 // ---------------------------------------------------------------------------
 template <bool INIT>
 __global__ void __launch_bounds__(RT_BLOCK)
-    k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch) {
+    k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t pass) {
   const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool in_range = slot < ch.slots;
   bool ended = false, goes_on = false;
@@ -147,7 +163,9 @@ __global__ void __launch_bounds__(RT_BLOCK)
   } else if (in_range) {
     const float4 rd = b.ray_d[slot];
     uint32_t depth = __float_as_uint(rd.w);
-    if (depth != WF_DEAD) {
+    if (depth != WF_DEAD && (depth & WF_SUSPENDED)) {
+      goes_on = true; // the ray is still being traced (k_wf_trace resumes it next round): nothing to shade yet
+    } else if (depth != WF_DEAD) {
       const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
       depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
       const float4 ro = b.ray_o[slot], h = b.hit[slot];
@@ -186,17 +204,30 @@ __global__ void __launch_bounds__(RT_BLOCK)
   const bool started = wf_regenerate(cam, pc, ch, b, ended, slot);
   if (ended && !started)
     b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
-  // live paths after this round, for the host's loop: one atomic per workgroup, striped
-  __shared__ uint32_t s_alive;
+  // Live paths after this pass: one atomic per workgroup on its stripe's counter (the host sums the stripes), and what
+  // the atomic returns places the workgroup's live slots in the stripe's segment of the live-slot list, which the
+  // trace pass walks instead of the slots once most of them are dead.
+  __shared__ uint32_t s_live[RT_BLOCK / 64], s_at;
+  const bool live = goes_on || started;
+  const unsigned long long lm = __ballot(live);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0)
+    s_live[wave] = (uint32_t)__popcll(lm);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) {
+    before += w < wave ? s_live[w] : 0u;
+    total += s_live[w];
+  }
+  if (total == 0)
+    return; // uniform over the workgroup
+  const uint32_t stripe = blockIdx.x % WF_STRIPES;
   if (threadIdx.x == 0)
-    s_alive = 0;
+    s_at = atomicAdd(b.ctrl + wf_alive_set(pass) + stripe * WF_PAD, total);
   __syncthreads();
-  const uint32_t n_wave = (uint32_t)__popcll(__ballot(goes_on || started));
-  if ((threadIdx.x & 63u) == 0 && n_wave)
-    atomicAdd(&s_alive, n_wave);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_alive)
-    atomicAdd(b.ctrl + WF_ALIVE + (blockIdx.x % WF_STRIPES) * WF_PAD, s_alive);
+  if (live && (pass >> 31)) // (bit 31: the host wants the list — not while every slot is refilled anyway)
+    b.live[(size_t)stripe * ch.list_span + s_at + before + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = slot;
 }
 
 // ---------------------------------------------------------------------------
@@ -206,9 +237,16 @@ __global__ void __launch_bounds__(RT_BLOCK)
 // per atomic from striped queue heads.
 // ---------------------------------------------------------------------------
 enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
-#define WF_GRAB 512u // measured 64 ... 4096 on full frames and on multi-GPU shards (tools/bench_shard.py): 512 is best on all
-                     // (256: -2 ... -5 %, 64-128: -40 % on a shard, 1024: -0 ... -12 %); asking for the next share in advance
-                     // (asynchronous atomic) made it no faster: a wave then holds two shares, which lengthens the tail
+// Slots per share.  Two costs pull against each other.  A share is what a wave works through alone: 256 slots are 4
+// rays per lane one after the other, about 0.4 ms, and the waves of a round finish up to that far apart (measured
+// with per-wave clocks, experiments/r02_trace_rounds/: with 512 the average wave of a 2 ms round was busy 76 % of it).
+// A SMALL share costs more than its atomic (two round trips at device scope, about 6 us): the lanes of a wave then
+// hold rays of several shares from different parts of the image, and the step loop itself slows down by 15 % at 64
+// — neighbouring slots are neighbouring pixels of one tile, and their rays share node records.  Measured 64 ... 4096 on
+// full frames and on shards (tools/bench_shard.py): 256 is best on all (512: -0.7 ... -4 %, 192 / 384: -1 ... -2 %,
+// 128: -5 %, 64: -17 %); shares that shrink towards the end of a band (guided self-scheduling) lost 2 ... 25 %, and so
+// did asking for the next share in advance (a wave then holds two) and skipping the look at the used-up bits.
+#define WF_GRAB 256u
 
 //
 // COOP: quad-cooperative record fetch.  A lane that gathers its own 64-byte record with four 16-byte loads costs the
@@ -228,7 +266,7 @@ enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
 template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_wf_trace(rt_dev_scene sc, rt_wf_geom geom, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter,
-               uint32_t regen_idle, uint32_t sched_arg) {
+               uint32_t regen_idle, uint32_t sched_arg, uint32_t susp_arg) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw; // [NLDS][BLOCK]
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -251,6 +289,22 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   uint32_t anyv = 0, fastv = 0;
   // the wave's share of the slot space (wave-uniform): [grab_next, grab_end), refilled from the band heads
   uint32_t grab_next = 0, grab_end = 0, band = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
+  // suspension (WF_SUSPENDED): susp_arg bits 0-7 = a wave with this many rays or fewer left and no fresh slots gives
+  // them up (0 = never), bit 8 = which of the two record pools this round writes (it reads the other)
+  // A wave suspends only after WF_SUSP_STEPS traversal steps of its own: every round then moves some ray forward, so
+  // the rounds end (a wave handed three resumed rays and nothing else would otherwise give them up again at once).
+  uint32_t susp_min = susp_arg & 0xFFu, q_empty = 0, steps = 0; // all wave-uniform
+  const uint32_t share = susp_arg >> 16; // bits 16-31: slots per share
+  // bit 9: walk the live-slot list of the shade pass before (band = stripe, its length from that pass's counters,
+  // bit 10 = which set) instead of the slots themselves
+  const bool by_list = (susp_arg & 0x200u) != 0u;
+  const uint32_t *const list_len = b.ctrl + wf_alive_set((susp_arg >> 10) & 1u);
+  const uint32_t band_span = by_list ? ch.list_span : ch.slot_span;
+  // bands this wave knows to be used up (those beyond the slot space from the start)
+  const uint32_t n_bands = by_list ? WF_STRIPES : (ch.slots + ch.slot_span - 1u) / ch.slot_span;
+  unsigned long long used_seen = n_bands >= 64u ? 0ull : ~((1ull << n_bands) - 1ull);
+  uint32_t *const pool_w = b.pool + (size_t)((susp_arg >> 8) & 1u) * b.pool_records * WF_REC_WORDS;
+  const uint32_t *const pool_r = b.pool + (size_t)(((susp_arg >> 8) & 1u) ^ 1u) * b.pool_records * WF_REC_WORDS;
 
   const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
   const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
@@ -273,53 +327,113 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       const unsigned long long mask = __ballot(need);
       if (mask == 0ull)
         break;
-      if (grab_next >= grab_end) { // the wave's share is used up: WF_GRAB more slots from a band head
-        // lane l looks at band l: one parallel load tells which bands have slots left (see wf_regenerate)
-        const uint32_t my_lo = lane * ch.slot_span;
-        const uint32_t my_hi = my_lo + ch.slot_span < ch.slots ? my_lo + ch.slot_span : ch.slots;
-        const uint32_t my_cnt = __hip_atomic_load(b.ctrl + WF_HEAD + lane * WF_PAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long avail = __ballot(my_lo < ch.slots && my_cnt < my_hi - my_lo);
+      if (grab_next >= grab_end) { // the wave's share is used up: `share` more slots from a band head
+        // which bands have slots left: one 64-bit word, a bit per band that a wave found used up (a look at the 64
+        // heads themselves cost 64 reads at device scope per share, as much as the rounds' tails)
+        // (looking only after the wave's own band has run out — one round trip per share instead of two — measured
+        // 4-12 % SLOWER: kept as it is)
+        used_seen |= __hip_atomic_load(reinterpret_cast<unsigned long long *>(b.ctrl + WF_USED), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long avail = ~used_seen;
         if (avail == 0ull) {
           if (need)
             state = WT_EXIT;
+          q_empty = 1u;
           break;
         }
         const unsigned long long rot = band ? ((avail >> band) | (avail << (64u - band))) : avail;
         band = (band + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
-        const uint32_t lo = band * ch.slot_span;
-        const uint32_t hi = lo + ch.slot_span < ch.slots ? lo + ch.slot_span : ch.slots;
+        const uint32_t lo = band * band_span;
+        const uint32_t hi = by_list ? lo + list_len[band * WF_PAD] : lo + band_span < ch.slots ? lo + band_span : ch.slots;
         uint32_t base = 0;
         if (lane == 0)
-          base = atomicAdd(b.ctrl + WF_HEAD + band * WF_PAD, WF_GRAB);
+          base = atomicAdd(b.ctrl + WF_HEAD + band * WF_PAD, share);
         base = (uint32_t)__shfl((int)base, 0, 64);
-        if (base >= hi - lo) // taken in between: look again
+        if (base >= hi - lo) { // the band is used up: say so, look again
+          used_seen |= 1ull << band;
+          if (lane == 0)
+            atomicOr(reinterpret_cast<unsigned long long *>(b.ctrl + WF_USED), 1ull << band);
           continue;
+        }
         grab_next = lo + base;
-        grab_end = grab_next + WF_GRAB < hi ? grab_next + WF_GRAB : hi;
+        grab_end = grab_next + share < hi ? grab_next + share : hi;
       }
       const uint32_t take = (uint32_t)__popcll(mask);
       if (need) {
-        const uint32_t s = grab_next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (s < grab_end) {
+        const uint32_t at = grab_next + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (at < grab_end) {
+          const uint32_t s = by_list ? b.live[at] : at;
+          // both halves of the ray at once (the origin of a dead slot is read for nothing: a second round trip for
+          // every live one costs more)
           const float4 rd = b.ray_d[s];
+          float4 ro = b.ray_o[s];
+          asm volatile("" : "+v"(ro.x), "+v"(ro.y), "+v"(ro.z));
           if (__float_as_uint(rd.w) != WF_DEAD) {
-            const float4 ro = b.ray_o[s];
             slot = s;
             wo = v3(ro.x, ro.y, ro.z), wd = v3(rd.x, rd.y, rd.z);
-            ref = sc.root_ref;
+            co = wo, cd = wd;
+            if (__float_as_uint(rd.w) & WF_SUSPENDED) { // a ray the round before gave up: take its state back
+              const uint32_t *rec = pool_r + (size_t)__float_as_uint(b.hit_v[s]) * WF_REC_WORDS;
+              const uint4 ra = *reinterpret_cast<const uint4 *>(rec), rb = *reinterpret_cast<const uint4 *>(rec + 4);
+              ref = ra.x, cur_inst = ra.y & 0x3FFFFFFFu, anyv = ra.y >> 31;
+              closest = __uint_as_float(ra.z), hit_u = __uint_as_float(ra.w), hit_v = __uint_as_float(rb.x);
+              hit_tri = rb.y, hit_inst = rb.z;
+              st.sp = 0;
+              for (uint32_t k = 0; k < rb.w; ++k)
+                st.push(rec[8u + k]);
+              if (ra.y & 0x40000000u) { // it was inside an instance: the same object-space ray as on entry
+                const float4 *q = reinterpret_cast<const float4 *>(sc.inst_trace + cur_inst);
+                float4 a = q[0], bb = q[1], c = q[2], e = q[3];
+                V3 c0 = v3(a.x, a.y, a.z), c1 = v3(bb.x, bb.y, bb.z), c2 = v3(c.x, c.y, c.z), c3 = v3(e.x, e.y, e.z);
+                co = mul_cols(c0, c1, c2, c3, wo, 1.f), cd = mul_cols(c0, c1, c2, c3, wd, 0.f);
+              }
+              reinterpret_cast<uint32_t *>(b.ray_d + s)[3] = __float_as_uint(rd.w) & ~WF_SUSPENDED;
+              state = WT_TRAVERSE;
+            } else {
+              ref = sc.root_ref;
+              closest = 1000.f; // RayTracing.slang:93-95
+              anyv = 0u;
+              cur_inst = 0;
+              st.sp = 0;
+              ++traced;
+              state = ref == RT_REF_NONE ? WT_FINISHED : WT_TRAVERSE;
+            }
             bool f2;
-            co = wo, cd = wd, prep_space<MODE>(co, cd, scene_ok, cinv, f2);
+            prep_space<MODE>(co, cd, scene_ok, cinv, f2);
             fastv = f2 ? 1u : 0u;
-            closest = 1000.f; // RayTracing.slang:93-95
-            anyv = 0u;
-            cur_inst = 0;
-            st.sp = 0;
-            ++traced;
-            state = ref == RT_REF_NONE ? WT_FINISHED : WT_TRAVERSE;
           }
         }
       }
       grab_next += take;
+    }
+    susp_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)susp_min);
+    if (q_empty && susp_min && steps >= WF_SUSP_STEPS) { // no fresh slots any more: every lane is traversing or done
+      const bool live = state == WT_TRAVERSE;
+      const unsigned long long lm = __ballot(live);
+      if (lm != 0ull && (uint32_t)__popcll(lm) <= susp_min) {
+        if (__ballot(live && st.sp > (int)WF_REC_STACK) != 0ull) {
+          susp_min = 0; // a stack deeper than a record: this wave sees its rays through
+        } else if (live) {
+          uint32_t tid = threadIdx.x;
+          asm volatile("" : "+v"(tid)); // keeps the record address out of the registers the step loop needs
+          const uint32_t r = blockIdx.x * BLOCK + tid;
+          uint32_t *rec = pool_w + (size_t)r * WF_REC_WORDS;
+          uint32_t inside = 0;
+          for (int k = 0; k < st.sp; ++k) {
+            const uint32_t e = k < NLDS ? st.lds[k * BLOCK] : st.spill[k - NLDS];
+            inside |= e == RT_REF_SENTINEL ? 0x40000000u : 0u;
+            rec[8 + k] = e;
+          }
+          *reinterpret_cast<uint4 *>(rec) = make_uint4(ref, cur_inst | inside | (anyv << 31), __float_as_uint(closest), __float_as_uint(hit_u));
+          *reinterpret_cast<uint4 *>(rec + 4) = make_uint4(__float_as_uint(hit_v), hit_tri, hit_inst, (uint32_t)st.sp);
+          b.hit_v[slot] = __uint_as_float(r);
+          uint32_t *dw = reinterpret_cast<uint32_t *>(b.ray_d + slot) + 3;
+          *dw = *dw | WF_SUSPENDED;
+          state = WT_EXIT;
+          if (lane == (uint32_t)__ffsll((long long)lm) - 1u)
+            atomicAdd(ray_counter + 1, (unsigned long long)__popcll(lm)); // statistics: rays suspended
+        }
+      }
     }
     if (__ballot(state != WT_EXIT) == 0ull)
       break;
@@ -331,8 +445,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       const uint32_t n1 = (uint32_t)__popcll(__ballot(kind == 1u));
       const uint32_t n2 = (uint32_t)__popcll(__ballot(kind == 2u));
       const uint32_t n3 = (uint32_t)__popcll(__ballot(kind == 3u));
-      if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle)
+      if (n1 + n2 + n3 == 0u || 64u - (n1 + n2 + n3) - n_done >= regen_idle || (q_empty && steps >= WF_SUSP_STEPS && n1 + n2 + n3 <= susp_min))
         break;
+      ++steps;
       const uint32_t s1 = n1 * w_pair, s2 = n2 * w_inst, s3 = n3 * w_leaf;
       bool do_pop = false;
       uint32_t sel;
@@ -549,13 +664,22 @@ __global__ void __launch_bounds__(RT_BLOCK)
 // ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
-size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots) {
+#ifndef RT_WF_MINW
+#define RT_WF_MINW 6 // resident waves per SIMD the trace kernel is built for
+#endif
+
+uint32_t rt_wf_pool_records(uint32_t cus) { // one record per lane of every trace wave that can be resident
+  return cus * RT_WF_MINW * 4u * 64u;
+}
+
+size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records) {
   return (size_t)slots * (5 * sizeof(float4) + sizeof(float)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) +
-         ((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t) +
+         ((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t) + ((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t) +
+         (size_t)2 * pool_records * WF_REC_WORDS * sizeof(uint32_t) +
          (size_t)tile_slots * sizeof(float4) + 16 * 256;
 }
 
-void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buffers &b) {
+void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t pool_records, rt_wf_buffers &b) {
   static_assert(WF_CTRL_WORDS <= RT_WF_CTRL_WORDS, "control block");
   char *p = static_cast<char *>(state_mem);
   auto take = [&](size_t bytes) {
@@ -572,12 +696,12 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buf
   b.hit_v = reinterpret_cast<float *>(take((size_t)slots * sizeof(float)));
   b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
   b.block_pos = reinterpret_cast<uint32_t *>(take(((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t)));
+  b.live = reinterpret_cast<uint32_t *>(take(((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t)));
+  b.pool = reinterpret_cast<uint32_t *>(take((size_t)2 * pool_records * WF_REC_WORDS * sizeof(uint32_t)));
+  b.pool_records = pool_records;
   b.slots = slots;
 }
 
-#ifndef RT_WF_MINW
-#define RT_WF_MINW 6 // resident waves per SIMD the trace kernel is built for
-#endif
 #define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per workgroup
 // the cooperative-fetch build: 12 KiB of stacks + 16.25 KiB of staging per workgroup, 5 workgroups per CU
 #define RT_WF_COOP_MINW 5
@@ -585,12 +709,12 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, rt_wf_buf
 
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
                                       const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
-                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, uint32_t cus,
-                                      hipStream_t stream) {
+                                      const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, const rt_wf_tuning &tune,
+                                      rt_wf_counts *counts, uint32_t cus, hipStream_t stream) {
   const uint32_t rows = rt_virtual_rows(pc);
   if (rows == 0 || pc.image_width == 0)
     return hipSuccess;
-  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG || pc.max_depth >= WF_HAS_ATT)
+  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG || pc.max_depth >= WF_SUSPENDED)
     return hipErrorInvalidValue;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint64_t tile_slots = (uint64_t)tiles_x * ((rows + 7u) >> 3) * 64u;
@@ -606,6 +730,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   // knobs: bits 8-15 regeneration threshold of the trace kernel, 16-27 vote weights, 28-30 join code, 31 no fast slab
   // default 24 idle lanes (C3, 256 spp: 4 -> 308 ms, 8 -> 301, 16 -> 289, 24 -> 282, 32 -> 292, 48 -> 327 per launch)
   const uint32_t regen_idle = ((knobs >> 8) & 0x7Fu) ? ((knobs >> 8) & 0x7Fu) : 24u;
+  // scheduling of the rounds (rt_wf_tuning; 0xFFFFFFFF = the measured defaults, rt_wavefront.h)
+  const uint32_t susp_lanes = tune.suspend_lanes == 0xFFFFFFFFu ? 32u : tune.suspend_lanes > 64u ? 64u : tune.suspend_lanes;
+  const uint32_t list_below = tune.list_percent == 0xFFFFFFFFu ? 75u : tune.list_percent;
+  const uint32_t full_share = tune.share == 0xFFFFFFFFu ? WF_GRAB : tune.share < 64u ? 64u : tune.share > 4096u ? 4096u : tune.share / 64u * 64u;
   const bool coop = (knobs & 0x8000u) != 0u; // knob bit 15: quad-cooperative fetch instead of per-lane gathers
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
   const size_t lds_bytes = coop ? (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES
@@ -615,10 +743,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   do {                                                                                                                 \
     if (coop)                                                                                                          \
       hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true>), dim3(blocks), dim3(RT_BLOCK), \
-                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched);                            \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                            \
     else                                                                                                               \
       hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS, false>), dim3(blocks), dim3(RT_BLOCK),     \
-                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched);                            \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                            \
   } while (0)
   auto span64 = [](uint64_t total) { // per-band share, a multiple of 64
     const uint64_t per = (total + WF_STRIPES - 1) / WF_STRIPES;
@@ -635,6 +763,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
     if (ch.slots > b.slots)
       ch.slots = b.slots / 64u * 64u;
     ch.slot_span = span64(ch.slots);
+    ch.list_span = ((ch.slots + RT_BLOCK - 1) / RT_BLOCK + WF_STRIPES - 1) / WF_STRIPES * RT_BLOCK;
     const bool first = s0 == 0, last = s0 + ch.cs == spp;
     if (pc.max_depth == 0) { // no bounce is traced: every sample contributes nothing (RayTracing.slang:92)
       if ((e = hipMemsetAsync(b.sr, 0, (size_t)ch.total * sizeof(float4), stream)) != hipSuccess)
@@ -646,10 +775,11 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
-      hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
-      while (true) {
+      hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+      bool have_list = false; // the last shade pass wrote the live-slot list
+      for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
         // live paths after the last shade: the host decides whether another round is needed
-        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + WF_ALIVE, WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + wf_alive_set(round), WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
           return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess)
           return e;
@@ -658,20 +788,42 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
           alive += h_ctrl[k * WF_PAD];
         if (alive == 0)
           break;
-        // reset the trace kernel's queue heads and the live counters (contiguous in the control block)
-        if ((e = hipMemsetAsync(b.ctrl + WF_HEAD, 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t), stream)) != hipSuccess)
+        // the next shade pass writes the live-slot list once this chunk has run out of new paths (until then every
+        // slot is refilled and the list would be all of them)
+        const bool make_list = list_below && alive < ch.slots;
+        // reset the trace kernel's queue heads and the counters of the NEXT shade pass (adjacent in the control block;
+        // this pass's counters stay: they are the lengths of the live-slot list)
+        if ((e = hipMemsetAsync(b.ctrl + ((round + 1u) & 1u ? WF_HEAD : WF_ALIVE0), 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t),
+                                stream)) != hipSuccess)
           return e;
-        // the grid scans ALL slots for live ones (dead slots cost a 16-byte read), so it is sized by the slots: sized
-        // by the live paths, a round with a handful of stragglers ran in one workgroup and took 12 ms
-        const uint64_t need = ((uint64_t)ch.slots + WF_GRAB - 1) / WF_GRAB; // one wave per WF_GRAB slots at least
+        // While most slots hold a path the trace pass walks the slots themselves (coalesced, no indirection; a dead
+        // slot costs a 16-byte read); once they thin out it walks the list of live slots the shade pass left, and
+        // the grid is sized by that list.
+        const bool by_list = have_list && alive * 100u < (uint64_t)ch.slots * list_below;
+        // (a short list goes out in smaller shares, down to one ray per lane: the last rounds are a matter of latency)
+        uint32_t share = full_share;
+        if (by_list && alive / (resident * (RT_BLOCK / 64u)) < share)
+          share = (uint32_t)(alive / (resident * (RT_BLOCK / 64u))) / 64u * 64u;
+        share = share < 64u ? 64u : share;
+        const uint64_t need = ((by_list ? alive : (uint64_t)ch.slots) + share - 1) / share; // one wave per share at least
         const uint32_t blocks = (uint32_t)(need / (RT_BLOCK / 64) + 1 < resident ? need / (RT_BLOCK / 64) + 1 : resident);
+        // rays may be suspended while the rounds are full (the next round comes anyway and carries them along); once
+        // the paths thin out every ray is seen through, or the stragglers would add rounds of their own
+        const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * RT_BLOCK <= b.pool_records
+                                   ? susp_lanes : 0u) | ((round & 1u) << 8) | (by_list ? 0x200u : 0u) | ((round & 1u) << 10) | (share << 16);
         if (pc.aabb_mode == RT_AABB_RCP)
           RT_WF_TRACE(RT_AABB_RCP);
         else
           RT_WF_TRACE(RT_AABB_DIV);
-        hipLaunchKernelGGL((k_wf_shade<false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch);
+        hipLaunchKernelGGL((k_wf_shade<false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                           (round + 1u) | (make_list ? 0x80000000u : 0u));
+        have_list = make_list;
         if ((e = hipGetLastError()) != hipSuccess)
           return e;
+        if (counts) {
+          ++counts->rounds;
+          counts->list_rounds += by_list ? 1u : 0u;
+        }
       }
     }
     hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,

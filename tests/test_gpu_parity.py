@@ -540,6 +540,50 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
         c.close()
 
 
+@pytest.mark.parametrize("suspend,listp,share", [(0, 0, 256), (64, 0, 64), (0, 100, 256), (64, 100, 64), (32, 75, 256), (8, 50, 512)])
+@pytest.mark.parametrize("scene", ["mixed", "chain"])
+def test_wavefront_suspended_rays_and_live_slot_list(scene, suspend, listp, share):
+    """Kernel 9's round scheduling — trace waves that give their last rays up (traversal state saved to HBM, resumed
+    next round, also from inside an instance and with stack entries beyond the LDS part) and trace passes that walk the
+    list of live slots — changes neither the image nor the ray count, whatever the thresholds; the counters show that
+    the paths under test were taken."""
+    c = _ffi.HipContext(0)
+    try:
+        if scene == "mixed":
+            sc = S.mixed_scene().build()
+            w, h = 136, 76
+            from raytracing_amd import renderer as R
+            cam = R.Renderer(w, h, device=None).camera_uniforms(R.Camera((3.5, 2.5, 4.5), (0, 0, 0), (0, 1, 0), 45.0))
+        else:
+            sc = _chain_scene().build()  # traversal stacks up to 37 entries: 21 of them beyond the 16 in LDS
+            w, h = 96, 40
+            cam = O.camera_uniforms((-1.0, 0.2, 0.1), (600.0, 0.0, 0.0), (0, 1, 0), 30.0, w, h)
+        c.upload_scene(sc)
+        c.set_kernel_variant(9)
+        c.set_wavefront_budget(8192, 1 << 30)  # 8 Ki slots for 93 K / 35 K paths: full rounds, then the thinning ones
+        c.wavefront_tuning(suspend, listp, share)
+        c.set_camera(cam)
+        c.resize(w, h)
+        c.reset_stats()
+        cn = O.Counters()
+        p = O.render_params(w, h, 0, 3, 8, rng_mode=T.RNG_PCG)
+        want = O.render(sc, cam, p, counters=cn, nthreads=8)
+        c.render(p)
+        _same_image(c.read_accum(w, h), want)
+        assert c.stats().rays_traced == cn.rays  # a resumed ray is not counted twice
+        rounds, list_rounds, suspended = c.wavefront_counts()
+        assert rounds >= 8
+        assert (list_rounds > 0) == (listp > 0), (rounds, list_rounds)
+        assert (suspended > 0) == (suspend > 0), (rounds, suspended)
+        # a second frame on top through the same state buffers, in two interleaved shards
+        for rb in (0, 8):
+            c.render(O.render_params(w, h, 1, 2, 5, rng_mode=T.RNG_PCG, row_begin=rb, row_end=h, row_group_stride=2))
+        O.render(sc, cam, O.render_params(w, h, 1, 2, 5, rng_mode=T.RNG_PCG), want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("coop", [0, 1])
 def test_wavefront_deep_stack_and_edge_scenes(ctx, coop):
     """Kernel 9's trace kernel keeps 16 stack entries in LDS: the 38-instance chain drives it to 37; scenes outside the

@@ -9,9 +9,9 @@ r = R.Renderer(1920, 1080, device=0)
 cam, n = bench.build_dragon_scene(R, r)
 r.set_option(R.OPT_SAMPLES_PER_PIXEL, 256); r.set_option(R.OPT_MAX_DEPTH, 8); r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
 ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
-for stride in (8, 4, 2, 1):
+for stride in [int(x) for x in os.environ.get('RT_STRIDES', '8,4,2,1').split(',')]:
     r.set_option(R.OPT_ROW_BEGIN, 0); r.set_option(R.OPT_ROW_END, 1080); r.set_option(R.OPT_ROW_GROUP_STRIDE, stride)
-    for variant in (8, 9):
+    for variant in [int(x) for x in os.environ.get('RT_KERNELS', '8,9').split(',')]:
         r.set_option(R.OPT_KERNEL_VARIANT, variant)
         best = None
         for rep in range(3):
