@@ -124,10 +124,14 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
  * _tuning: a trace wave that is out of fresh slots gives up its rays once `suspend_lanes` or fewer are left (their
  * traversal state is saved; they resume next round; 0 = never; default 32); the trace pass walks the list of live
  * slots once fewer than `list_percent` % of the slots hold a path (0 = never; default 75); `share` = slots a wave
- * takes per atomic (multiple of 64, default 256).  0xFFFFFFFF = default.  The image does not depend on any of them.
- * _counts: since rt_reset_stats — trace + shade rounds, rounds whose trace pass walked the list, rays suspended. */
-int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share);
-int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays);
+ * takes per atomic (multiple of 64, default 256); once `finish_paths` paths or fewer are alive one kernel sees them
+ * through to their ends (0 = never; default 768 per CU).  0xFFFFFFFF = default.  The image does not depend on any of them.
+ * _counts: since rt_reset_stats — trace + shade rounds, rounds whose trace pass walked the list, rays suspended, paths handed to the
+ * finishing kernel. */
+int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share,
+                              uint32_t finish_paths);
+int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
+                              uint64_t *finished_paths);
 
 /* Measurement aid (no counterpart in the reference): every lane of `blocks`
  * 256-thread workgroups walks the uploaded node records for `steps` dependent,

@@ -85,8 +85,8 @@ def lib():
     L.rt_debug_fast_div.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rt_build_tlas_cluster.argtypes = [vp, vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
-    L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32]
-    L.rt_debug_wavefront_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32, u32]
+    L.rt_debug_wavefront_counts.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -211,14 +211,15 @@ class HipContext:
     def set_wavefront_budget(self, paths_in_flight, result_bytes):
         _check(lib().rt_set_wavefront_budget(self._h, paths_in_flight, result_bytes))
 
-    def wavefront_tuning(self, suspend_lanes=0xFFFFFFFF, list_percent=0xFFFFFFFF, share=0xFFFFFFFF):
-        _check(lib().rt_debug_wavefront_tuning(self._h, suspend_lanes, list_percent, share))
+    def wavefront_tuning(self, suspend_lanes=0xFFFFFFFF, list_percent=0xFFFFFFFF, share=0xFFFFFFFF, finish_paths=0xFFFFFFFF):
+        _check(lib().rt_debug_wavefront_tuning(self._h, suspend_lanes, list_percent, share, finish_paths))
 
     def wavefront_counts(self):
-        """(rounds, rounds whose trace pass walked the live-slot list, rays suspended) since reset_stats."""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        _check(lib().rt_debug_wavefront_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        """(rounds, rounds whose trace pass walked the live-slot list, rays suspended, paths handed to the finishing
+        kernel) since reset_stats."""
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().rt_debug_wavefront_counts(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))

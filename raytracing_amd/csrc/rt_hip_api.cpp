@@ -897,18 +897,21 @@ int rt_debug_probe_walk(rt_ctx *ctx, uint32_t blocks, uint32_t steps, uint32_t l
   return RT_OK;
 }
 
-int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share) {
+int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share,
+                              uint32_t finish_paths) {
   if (!ctx)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_tuning: NULL context");
   ctx->wf_tuning.suspend_lanes = suspend_lanes;
   ctx->wf_tuning.list_percent = list_percent;
   ctx->wf_tuning.share = share;
+  ctx->wf_tuning.finish_paths = finish_paths;
   ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old settings
   return RT_OK;
 }
 
-int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays) {
-  if (!ctx || !rounds || !list_rounds || !suspended_rays)
+int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
+                              uint64_t *finished_paths) {
+  if (!ctx || !rounds || !list_rounds || !suspended_rays || !finished_paths)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_counts: NULL argument");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -917,6 +920,7 @@ int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_roun
   *rounds = ctx->wf_counts.rounds;
   *list_rounds = ctx->wf_counts.list_rounds;
   *suspended_rays = susp;
+  *finished_paths = ctx->wf_counts.finished_paths;
   return RT_OK;
 }
 

@@ -47,10 +47,13 @@ struct rt_wf_tuning {
   uint32_t list_percent = 0xFFFFFFFFu;  // the trace pass walks the live-slot list once fewer than this % of the slots are
                                         // alive (0 = never; default 75)
   uint32_t share = 0xFFFFFFFFu;         // slots a wave takes per atomic (a multiple of 64; default 256)
+  uint32_t finish_paths = 0xFFFFFFFFu;  // once this many paths or fewer are alive one kernel sees them through, trace and
+                                        // shade in a loop per lane (0 = never; default 768 per CU)
 };
 struct rt_wf_counts { // statistics, summed over launches
   uint64_t rounds = 0;      // trace + shade rounds
   uint64_t list_rounds = 0; // of these, rounds whose trace pass walked the live-slot list
+  uint64_t finished_paths = 0; // paths alive when k_wf_finish took over
 };
 
 // One rt_render launch through the pipeline.  d_counter: two words, rays traced and rays suspended.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the

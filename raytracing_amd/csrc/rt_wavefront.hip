@@ -629,6 +629,77 @@ __global__ void __launch_bounds__(BLOCK, MINW)
 }
 
 // ---------------------------------------------------------------------------
+// k_wf_finish: the last paths of a chunk, each seen through to its end by one lane — trace, shade, trace, ... in one
+// kernel, as k_render_v0 does per pixel.  The last rounds of a chunk hold a few thousand paths and last as long as
+// their longest ray each (0.3 ms, plus a shade pass and a host round trip); here the remaining bounces of a path cost
+// their own rays only.  Walks the live-slot list.  A lane whose path ends starts the next path of its slot's shade
+// workgroup, if that still has ids (the same strided share as wf_regenerate, one id per atomic), so the chunk is
+// complete when the kernel ends whatever was left.  No slot may be suspended (the host checks).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK)
+    k_wf_finish(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t set,
+                uint32_t shade_blocks, unsigned long long *ray_counter) {
+  __shared__ uint32_t lds_stack[RT_LDS_STACK * RT_BLOCK];
+  RT_STACK_DECL(RT_BLOCK, RT_LDS_STACK, st, lds_stack);
+  // entry -> (stripe, position): the stripes' lengths differ, so a workgroup walks one stripe (blockIdx.y)
+  const uint32_t stripe = blockIdx.y, at = blockIdx.x * RT_BLOCK + threadIdx.x;
+  uint32_t traced = 0;
+  if (at < b.ctrl[wf_alive_set(set) + stripe * WF_PAD]) {
+    const uint32_t slot = b.live[(size_t)stripe * ch.list_span + at];
+    const float4 rd = b.ray_d[slot], ro = b.ray_o[slot];
+    uint32_t depth = __float_as_uint(rd.w), id = __float_as_uint(ro.w);
+    const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
+    depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
+    const float4 at4 = has_att ? b.att[slot] : make_float4(1.f, 1.f, 1.f, 0.f);
+    const float4 ra = has_rad ? b.rad[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+    Path p;
+    p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
+    p.attenuation = v3(at4.x, at4.y, at4.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
+    const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+    const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+    const uint32_t blk = slot / RT_BLOCK; // the shade workgroup that owns the slot, and its share of the ids
+    while (true) {
+      uint32_t x, y, sample;
+      wf_pixel_of(pc, ch, id, x, y, sample);
+      Rng rng = make_rng(pc, x, y);
+      rng.sample = pc.frame_index * spp + sample;
+      for (; depth < pc.max_depth; ++depth) { // (a path in a slot has depth < max_depth)
+        rng.set_slot(depth + 1u);
+        Hit hit;
+        const bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
+        ++traced;
+        if (!shade(sc, pc.flags, any, hit, rng, p))
+          break;
+      }
+      b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+      // the next path of the workgroup's share, if any (ids on tile padding are skipped)
+      bool started = false;
+      while (true) {
+        const uint32_t q = atomicAdd(b.block_pos + blk, 1u);
+        const uint64_t id64 = ((uint64_t)blk + (uint64_t)(q >> 6) * shade_blocks) * 64u + (q & 63u);
+        if (id64 >= ch.total)
+          break;
+        id = (uint32_t)id64;
+        wf_pixel_of(pc, ch, id, x, y, sample);
+        if (x < pc.image_width && y < pc.row_end) {
+          rng = make_rng(pc, x, y);
+          rng.sample = pc.frame_index * spp + sample;
+          rng.set_slot(0);
+          camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          depth = 0;
+          started = true;
+          break;
+        }
+      }
+      if (!started)
+        break;
+    }
+    b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
+  }
+  count_rays(ray_counter, traced);
+}
+
+// ---------------------------------------------------------------------------
 // k_wf_resolve: one lane per pixel; radiance = sum of the chunk's sample radiances in sample order on top of the
 // chunks before (RayTracing.slang:170), the last chunk folds it into the running mean (:174-179).
 // ---------------------------------------------------------------------------
@@ -733,6 +804,9 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   // scheduling of the rounds (rt_wf_tuning; 0xFFFFFFFF = the measured defaults, rt_wavefront.h)
   const uint32_t susp_lanes = tune.suspend_lanes == 0xFFFFFFFFu ? 32u : tune.suspend_lanes > 64u ? 64u : tune.suspend_lanes;
   const uint32_t list_below = tune.list_percent == 0xFFFFFFFFu ? 75u : tune.list_percent;
+  // (half a path per lane the trace kernel can have resident: C3 shard of an eighth, ms per launch, finisher from
+  // 0 / 50 K / 200 K / 500 K / 1 M / 2 M / 4 M paths on: 39.9 / 39.7 / 39.0 / 39.4 / 40.1 / 41.6 / 44.8; full frame 255.3 ... 254.3)
+  const uint64_t finish_paths = tune.finish_paths == 0xFFFFFFFFu ? (uint64_t)cus * RT_WF_MINW * 4u * 32u : tune.finish_paths;
   const uint32_t full_share = tune.share == 0xFFFFFFFFu ? WF_GRAB : tune.share < 64u ? 64u : tune.share > 4096u ? 4096u : tune.share / 64u * 64u;
   const bool coop = (knobs & 0x8000u) != 0u; // knob bit 15: quad-cooperative fetch instead of per-lane gathers
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
@@ -777,6 +851,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
       hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
       bool have_list = false; // the last shade pass wrote the live-slot list
+      bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
       for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
         // live paths after the last shade: the host decides whether another round is needed
         if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + wf_alive_set(round), WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
@@ -791,6 +866,18 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         // the next shade pass writes the live-slot list once this chunk has run out of new paths (until then every
         // slot is refilled and the list would be all of them)
         const bool make_list = list_below && alive < ch.slots;
+        if (have_list && !maybe_suspended && alive <= finish_paths) { // the last few: one kernel sees them through
+          uint32_t longest = 0;
+          for (uint32_t k = 0; k < WF_STRIPES; ++k)
+            longest = h_ctrl[k * WF_PAD] > longest ? h_ctrl[k * WF_PAD] : longest;
+          hipLaunchKernelGGL(k_wf_finish, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream, sc, cam,
+                             pc, b, ch, round, shade_blocks, d_counter);
+          if ((e = hipGetLastError()) != hipSuccess)
+            return e;
+          if (counts)
+            counts->finished_paths += alive;
+          break;
+        }
         // reset the trace kernel's queue heads and the counters of the NEXT shade pass (adjacent in the control block;
         // this pass's counters stay: they are the lengths of the live-slot list)
         if ((e = hipMemsetAsync(b.ctrl + ((round + 1u) & 1u ? WF_HEAD : WF_ALIVE0), 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t),
@@ -820,6 +907,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         have_list = make_list;
         if ((e = hipGetLastError()) != hipSuccess)
           return e;
+        maybe_suspended = (susp & 0xFFu) != 0u;
         if (counts) {
           ++counts->rounds;
           counts->list_rounds += by_list ? 1u : 0u;

@@ -540,13 +540,16 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
         c.close()
 
 
-@pytest.mark.parametrize("suspend,listp,share", [(0, 0, 256), (64, 0, 64), (0, 100, 256), (64, 100, 64), (32, 75, 256), (8, 50, 512)])
+@pytest.mark.parametrize("suspend,listp,share,finish", [(0, 0, 256, 0), (64, 0, 64, 0), (0, 100, 256, 0), (64, 100, 64, 0),
+                                                         (32, 75, 256, 0), (8, 50, 512, 300), (64, 100, 64, 3000),
+                                                         (0, 100, 256, 1 << 30)])
 @pytest.mark.parametrize("scene", ["mixed", "chain"])
-def test_wavefront_suspended_rays_and_live_slot_list(scene, suspend, listp, share):
+def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, listp, share, finish):
     """Kernel 9's round scheduling — trace waves that give their last rays up (traversal state saved to HBM, resumed
     next round, also from inside an instance and with stack entries beyond the LDS part) and trace passes that walk the
-    list of live slots — changes neither the image nor the ray count, whatever the thresholds; the counters show that
-    the paths under test were taken."""
+    list of live slots, and the kernel that sees the last paths through (from a few hundred left to everything after
+    the first thinning round, new paths of unfinished shares included) — changes neither the image nor the ray count,
+    whatever the thresholds; the counters show that the paths under test were taken."""
     c = _ffi.HipContext(0)
     try:
         if scene == "mixed":
@@ -561,7 +564,7 @@ def test_wavefront_suspended_rays_and_live_slot_list(scene, suspend, listp, shar
         c.upload_scene(sc)
         c.set_kernel_variant(9)
         c.set_wavefront_budget(8192, 1 << 30)  # 8 Ki slots for 93 K / 35 K paths: full rounds, then the thinning ones
-        c.wavefront_tuning(suspend, listp, share)
+        c.wavefront_tuning(suspend, listp, share, finish)
         c.set_camera(cam)
         c.resize(w, h)
         c.reset_stats()
@@ -571,9 +574,11 @@ def test_wavefront_suspended_rays_and_live_slot_list(scene, suspend, listp, shar
         c.render(p)
         _same_image(c.read_accum(w, h), want)
         assert c.stats().rays_traced == cn.rays  # a resumed ray is not counted twice
-        rounds, list_rounds, suspended = c.wavefront_counts()
-        assert rounds >= 8
-        assert (list_rounds > 0) == (listp > 0), (rounds, list_rounds)
+        rounds, list_rounds, suspended, finished = c.wavefront_counts()
+        assert rounds >= (8 if finish < (1 << 30) else 2)
+        if finish < (1 << 30):  # (with everything handed to the finisher no trace pass is left to walk the list)
+            assert (list_rounds > 0) == (listp > 0), (rounds, list_rounds)
+        assert (finished > 0) == (finish > 0), (rounds, finished)
         assert (suspended > 0) == (suspend > 0), (rounds, suspended)
         # a second frame on top through the same state buffers, in two interleaved shards
         for rb in (0, 8):

@@ -9,6 +9,8 @@ r = R.Renderer(1920, 1080, device=0)
 cam, n = bench.build_dragon_scene(R, r)
 r.set_option(R.OPT_SAMPLES_PER_PIXEL, 256); r.set_option(R.OPT_MAX_DEPTH, 8); r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
 ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
+if os.environ.get("RT_WF_TUNING"):  # suspend_lanes,list_percent,share,finish_paths (-1 = default)
+    _ffi._check(L.rt_debug_wavefront_tuning(ctx, *[int(x) & 0xFFFFFFFF for x in os.environ["RT_WF_TUNING"].split(",")]))
 for stride in [int(x) for x in os.environ.get('RT_STRIDES', '8,4,2,1').split(',')]:
     r.set_option(R.OPT_ROW_BEGIN, 0); r.set_option(R.OPT_ROW_END, 1080); r.set_option(R.OPT_ROW_GROUP_STRIDE, stride)
     for variant in [int(x) for x in os.environ.get('RT_KERNELS', '8,9').split(',')]:
