@@ -206,6 +206,7 @@ def main():
         _ffi._check(L.rt_set_stream(ctx, C.c_void_p(s_render.cuda_stream)))
         gather = sharding.InterleavedGather(H, W, device="cuda")
         comm_done = [None, None]
+    torch.cuda.synchronize()  # torch filled these buffers on ITS stream; everything below runs on other streams
     setup_s = time.time() - t_setup
 
     def step():
@@ -304,6 +305,7 @@ def main():
         sample = [g for g in range(groups) if g % world != 0]
         sample = sample[:: max(1, len(sample) // 5)][:5]
         chk = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the launches below on the library's
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(chk.data_ptr()), W, H))
         camu = r.camera_uniforms(cam)
         _ffi._check(L.rt_set_camera(ctx, C.byref(camu)))
@@ -370,6 +372,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         # parity spot check: the first oracle frame vs the same launch on the GPU
         chk = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the launches below on the library's
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(chk.data_ptr()), W, H))
         p0 = O.render_params(W, H, 0, cpu_sqrt, args.depth, rng_mode=rng_mode, aabb_mode=aabb_mode)
         _ffi._check(L.rt_set_camera(ctx, C.byref(camu)))
