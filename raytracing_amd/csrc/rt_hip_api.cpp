@@ -75,6 +75,8 @@ struct rt_ctx {
   DevBuf<rt_triangle_shading> shading;
   DevBuf<uint8_t> texels;
   DevBuf<unsigned long long> counter;
+  DevBuf<rt_ray> trace_rays; // staging of rt_trace_closest (host arrays in and out)
+  DevBuf<rt_hit> trace_hits;
   DevBuf<uint32_t> queue; // pixel queue head of the persistent kernel
   uint32_t cus = 0;       // compute units of the device
   // kernel 9 (rt_wavefront.hip): path state, per-path results and the pinned read-back of the list lengths
@@ -398,6 +400,8 @@ int rt_destroy(rt_ctx *ctx) {
   ctx->shading.release();
   ctx->texels.release();
   ctx->counter.release();
+  ctx->trace_rays.release();
+  ctx->trace_hits.release();
   ctx->queue.release();
   ctx->accum_own.release();
   ctx->wf_state.release();
@@ -776,14 +780,13 @@ int rt_trace_closest(rt_ctx *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, 
   if (n == 0)
     return RT_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  rt_ray *d_rays = nullptr;
-  rt_hit *d_hits = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(rt_ray)));
-  hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(rt_hit));
-  if (e != hipSuccess) {
-    (void)hipFree(d_rays);
+  // staging buffers of the context: they grow to the largest batch seen and stay (no allocation per call)
+  HIP_TRY(hipStreamSynchronize(ctx->stream)); // a growing buffer is freed: nothing in flight may still use it
+  if (ctx->trace_rays.reserve(n) != hipSuccess || ctx->trace_hits.reserve(n) != hipSuccess)
     return fail(RT_ERR_OUT_OF_MEMORY, "rt_trace_closest: hipMalloc failed");
-  }
+  rt_ray *d_rays = ctx->trace_rays.ptr;
+  rt_hit *d_hits = ctx->trace_hits.ptr;
+  hipError_t e;
   int rc = RT_OK;
   e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess)
@@ -791,8 +794,6 @@ int rt_trace_closest(rt_ctx *ctx, const rt_ray *rays, uint64_t n, rt_hit *hits, 
   if (e == hipSuccess && rc == RT_OK)
     e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
   hipError_t es = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_rays);
-  (void)hipFree(d_hits);
   if (rc != RT_OK)
     return rc;
   if (e != hipSuccess || es != hipSuccess)
