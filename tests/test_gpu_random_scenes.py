@@ -103,3 +103,38 @@ def test_random_scene_images_and_hits_are_bit_exact(ctx, seed):
         for f in ("t", "u", "v"):
             assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (seed, mode, f)
         assert np.array_equal(a["tri_id"], b["tri_id"]) and np.array_equal(a["inst_id"], b["inst_id"]), (seed, mode)
+
+
+@pytest.mark.parametrize("seed", range(100, 136))
+def test_random_scene_kernel9_round_scheduling_is_invisible(seed):
+    """The same generated scenes through kernel 9 (keyed PCG RNG) with random path-slot budgets and random settings of
+    its round scheduling (suspended rays, live-slot list, share size, finishing kernel): the image equals the
+    oracle's bit for bit and the rays counter equals the oracle's count, whatever the schedule."""
+    r, (eye, look, up, fov), rng = _random_scene(seed)
+    sc = r.build()
+    c = _ffi.HipContext(0)
+    try:
+        c.upload_scene(sc)
+        w, h = int(rng.integers(40, 160)), int(rng.integers(24, 100))
+        cam = O.camera_uniforms(eye, look, up, fov, w, h)
+        c.set_camera(cam)
+        c.resize(w, h)
+        sqrt_spp, depth = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 5, 8, 17]))
+        aabb = int(rng.choice([T.AABB_DIV, T.AABB_DIV, T.AABB_RCP]))
+        c.set_kernel_variant(9)
+        c.set_wavefront_budget(int(rng.choice([256, 1024, 4096, 1 << 14, 1 << 20])), int(rng.choice([1 << 20, 1 << 30])))
+        tuning = (int(rng.choice([0, 4, 32, 64])), int(rng.choice([0, 50, 100])), int(rng.choice([64, 128, 256, 1024])),
+                  int(rng.choice([0, 100, 5000, 1 << 30])))
+        c.wavefront_tuning(*tuning)
+        c.reset_stats()
+        cn = O.Counters()
+        want = np.zeros((h, w, 4), np.float32)
+        for frame in range(int(rng.integers(1, 3))):
+            p = O.render_params(w, h, frame, sqrt_spp, depth, rng_mode=T.RNG_PCG, aabb_mode=aabb)
+            c.render(p)
+            O.render(sc, cam, p, want, counters=cn, nthreads=8)
+        got = c.read_accum(w, h)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, tuning, sqrt_spp, depth, aabb)
+        assert c.stats().rays_traced == cn.rays, (seed, tuning)
+    finally:
+        c.close()
