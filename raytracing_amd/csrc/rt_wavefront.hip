@@ -288,7 +288,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   uint32_t hit_tri = 0, hit_inst = 0;
   uint32_t anyv = 0, fastv = 0;
   // the wave's share of the slot space (wave-uniform): [grab_next, grab_end), refilled from the band heads
-  uint32_t grab_next = 0, grab_end = 0, band = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
+  // (readfirstlane / readlane below: these values are the same in all lanes, and saying so keeps the whole share
+  // bookkeeping in scalar registers — 7 vector registers less)
+  uint32_t grab_next = 0, grab_end = 0;
+  uint32_t band = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES));
   // suspension (WF_SUSPENDED): susp_arg bits 0-7 = a wave with this many rays or fewer left and no fresh slots gives
   // them up (0 = never), bit 8 = which of the two record pools this round writes (it reads the other)
   // A wave suspends only after WF_SUSP_STEPS traversal steps of its own: every round then moves some ray forward, so
@@ -332,8 +335,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         // heads themselves cost 64 reads at device scope per share, as much as the rounds' tails)
         // (looking only after the wave's own band has run out — one round trip per share instead of two — measured
         // 4-12 % SLOWER: kept as it is)
-        used_seen |= __hip_atomic_load(reinterpret_cast<unsigned long long *>(b.ctrl + WF_USED), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long seen_now = __hip_atomic_load(reinterpret_cast<unsigned long long *>(b.ctrl + WF_USED),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        used_seen |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen_now) |
+                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seen_now >> 32)) << 32);
         const unsigned long long avail = ~used_seen;
         if (avail == 0ull) {
           if (need)
@@ -344,11 +349,12 @@ __global__ void __launch_bounds__(BLOCK, MINW)
         const unsigned long long rot = band ? ((avail >> band) | (avail << (64u - band))) : avail;
         band = (band + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
         const uint32_t lo = band * band_span;
-        const uint32_t hi = by_list ? lo + list_len[band * WF_PAD] : lo + band_span < ch.slots ? lo + band_span : ch.slots;
+        const uint32_t hi = by_list ? lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)list_len[band * WF_PAD])
+                                    : lo + band_span < ch.slots ? lo + band_span : ch.slots;
         uint32_t base = 0;
         if (lane == 0)
           base = atomicAdd(b.ctrl + WF_HEAD + band * WF_PAD, share);
-        base = (uint32_t)__shfl((int)base, 0, 64);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
         if (base >= hi - lo) { // the band is used up: say so, look again
           used_seen |= 1ull << band;
           if (lane == 0)
