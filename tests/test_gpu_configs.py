@@ -215,3 +215,36 @@ def test_c5_dragon_4k_defocus_pcg_sharded():
     pin = R.Camera(tuple(cam.c.position), tuple(cam.c.look_at), tuple(cam.c.v_up), cam.c.fov)
     assert not _same(a, _launch(r, pin, _ffi.KERNEL_VARIANT_AUTO))
     r.shutdown()
+
+
+def test_c3_fixed_ray_sets_a_million_camera_and_a_million_secondary_rays():
+    """SURVEY.md 8(d), correctness gate (1): (t bits, tri_id, inst_id) — and u, v — identical CPU <-> HIP on fixed ray
+    sets on the C3 scene: the 1.05 M camera rays of a 1366x768 frame and the 1.1 M cosine-scattered rays of their first
+    three bounces (frame 7 seeds the RNG), closest hits through the C ABI's rt_trace_closest against the oracle's."""
+    import bench
+    w, h = 1366, 768
+    r = R.Renderer(w, h, device=0)
+    cam, n_tris = bench.build_dragon_scene(R, r)
+    assert n_tris == 870402
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1)
+    r.render(cam)  # uploads the scene
+    r.wait()
+    sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
+    ctx = C.c_void_p(r.hip_context_handle())
+    L = _ffi.lib()
+    pr = O.render_params(w, h, 7, 1, 8)
+    total = 0
+    for bounce in (0, 1, 2, 3):
+        rays = O.gen_rays(sa, camu, pr, bounce)
+        if bounce == 0:
+            assert len(rays) == w * h
+        total += len(rays)
+        want = O.trace_closest(sa, rays, T.AABB_DIV)
+        got = np.zeros(len(rays), T.hit_dtype)
+        _ffi._check(L.rt_trace_closest(ctx, T.ptr(rays), len(rays), T.ptr(got), T.AABB_DIV))
+        for f in ("t", "u", "v"):
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), (bounce, f)
+        assert np.array_equal(got["tri_id"], want["tri_id"]) and np.array_equal(got["inst_id"], want["inst_id"]), bounce
+        assert (want["tri_id"] != T.INVALID_ID).mean() > 0.2, bounce
+    assert total - w * h > 1_000_000  # secondary rays
+    r.shutdown()
