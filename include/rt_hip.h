@@ -114,7 +114,7 @@ int rt_reset_stats(rt_ctx *ctx);
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 
 /* Sizing of kernel 9's HBM state (no counterpart in the reference): at most `paths_in_flight` path slots of 88 B
- * (default 2^26 = 64 Mi paths, 5.9 GB; up to 2^30 — a launch uses an eighth of its paths, at least 2^20, at most this)
+ * (default 2^26 = 64 Mi paths, 5.9 GB; up to 2^30 — a launch uses a sixth of its paths, at least 2^20, at most this)
  * and `result_bytes` for the per-path sample radiances of one sample chunk (16 B per path, default 10 GiB: a
  * 1920x1080 launch of 256 spp in one chunk; larger launches run in chunks of whole samples).
  * Takes effect at the next launch. */

@@ -664,14 +664,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     const uint32_t rows = rt_virtual_rows(pc);
     const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
     const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
-    // paths in flight: an eighth of the chunk's paths (measured on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
+    // paths in flight: a sixth of the chunk's paths (shards of 6.6e7 / 1.3e8 paths, ms per launch with 1/8, 1/7, 1/6,
+    // 1/5, 1/4, 1/3: 38.8 / 38.3 / 37.6 / 37.6 / 38.1 / 37.9 and 69.5 / 68.6 / 68.5 / 69.1 / 70.4 / 71.4; earlier, on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
     // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
     uint64_t chunk_paths = tile_slots * spp;
     if (chunk_paths * 16 > ctx->wf_sr_bytes)
       chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
     if (chunk_paths < tile_slots)
       chunk_paths = tile_slots;
-    uint64_t want_slots = (chunk_paths / 8 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
+    uint64_t want_slots = (chunk_paths / 6 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
     if (want_slots < (1u << 20))
       want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
     if (want_slots > ctx->wf_slots)
