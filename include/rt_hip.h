@@ -115,8 +115,9 @@ int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 
 /* Sizing of kernel 9's HBM state (no counterpart in the reference): at most `paths_in_flight` path slots of 88 B
  * (default 2^26 = 64 Mi paths, 5.9 GB; up to 2^30 — a launch uses a sixth of its paths, at least 2^20, at most this)
- * and `result_bytes` for the per-path sample radiances of one sample chunk (16 B per path, default 10 GiB: a
- * 1920x1080 launch of 256 spp in one chunk; larger launches run in chunks of whole samples).
+ * and `result_bytes` for the per-path sample radiances of one sample chunk (16 B per path, default 40 GiB,
+ * allocated as far as a launch needs it: a 1920x1080 launch of 1024 spp in one chunk; larger launches run in chunks of
+ * whole samples, each with its own thinning rounds).
  * Takes effect at the next launch. */
 int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t result_bytes);
 

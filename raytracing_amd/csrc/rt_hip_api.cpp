@@ -88,7 +88,8 @@ struct rt_ctx {
   uint64_t wf_tile_slots = 0;
   uint32_t wf_slots = 1u << 26;          // most paths in flight (rt_set_wavefront_budget): 64 Mi slots = 5.6 GB of state
   uint32_t wf_capacity = 0;              // slots the state allocation holds
-  uint64_t wf_sr_bytes = 10ull << 30;    // result buffer: 16 B per path of a sample chunk
+  uint64_t wf_sr_bytes = 40ull << 30;    // result buffer: 16 B per path of a sample chunk; allocated as needed (a 1080p
+                                         // frame of 1024 spp in one chunk: 984 ms against 1020 ms in four chunks of 10 GiB)
   uint32_t *wf_h_ctrl = nullptr;
   rt_wf_tuning wf_tuning;                // rt_debug_wavefront_tuning
   rt_wf_counts wf_counts;                // since rt_reset_stats
@@ -667,11 +668,28 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     // paths in flight: a sixth of the chunk's paths (shards of 6.6e7 / 1.3e8 paths, ms per launch with 1/8, 1/7, 1/6,
     // 1/5, 1/4, 1/3: 38.8 / 38.3 / 37.6 / 37.6 / 38.1 / 37.9 and 69.5 / 68.6 / 68.5 / 69.1 / 70.4 / 71.4; earlier, on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
     // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
-    uint64_t chunk_paths = tile_slots * spp;
-    if (chunk_paths * 16 > ctx->wf_sr_bytes)
-      chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
-    if (chunk_paths < tile_slots)
-      chunk_paths = tile_slots;
+    // The result buffer first: everything in one chunk if the budget allows, else chunks of whole samples.  If the
+    // device cannot give that much (other tenants), the budget is halved until it can, and stays there.
+    uint64_t chunk_paths;
+    while (true) {
+      chunk_paths = tile_slots * spp;
+      if (chunk_paths * 16 > ctx->wf_sr_bytes)
+        chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
+      if (chunk_paths < tile_slots)
+        chunk_paths = tile_slots; // at least one sample per chunk
+      if (ctx->wf_sr.ptr && ctx->wf.sr_paths >= chunk_paths)
+        break;
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      const hipError_t ae = ctx->wf_sr.reserve((size_t)chunk_paths * 16);
+      ctx->wf.sr = reinterpret_cast<float4 *>(ctx->wf_sr.ptr);
+      ctx->wf.sr_paths = ae == hipSuccess ? chunk_paths : 0;
+      if (ae == hipSuccess)
+        break;
+      (void)hipGetLastError(); // (the failed allocation's sticky error)
+      if (chunk_paths == tile_slots)
+        return fail(RT_ERR_OUT_OF_MEMORY, "rt_render: no device memory for kernel 9's result buffer (one sample per pixel)");
+      ctx->wf_sr_bytes = chunk_paths * 16 / 2;
+    }
     uint64_t want_slots = (chunk_paths / 6 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
     if (want_slots < (1u << 20))
       want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
@@ -709,17 +727,6 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       ctx->wf_geom_desc.pairs_off = 0;
       ctx->wf_geom_desc.tris_off = (uint32_t)pair_bytes;
       ctx->wf_geom_dirty = false;
-    }
-    uint64_t sr_paths = tile_slots * spp; // everything in one chunk if the budget allows
-    if (sr_paths * 16 > ctx->wf_sr_bytes)
-      sr_paths = (ctx->wf_sr_bytes / 16 / tile_slots) * tile_slots;
-    if (sr_paths < tile_slots)
-      sr_paths = tile_slots; // at least one sample per chunk
-    if (!ctx->wf_sr.ptr || ctx->wf.sr_paths < sr_paths) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx->wf_sr.reserve((size_t)sr_paths * 16));
-      ctx->wf.sr = reinterpret_cast<float4 *>(ctx->wf_sr.ptr);
-      ctx->wf.sr_paths = sr_paths;
     }
   }
   EventPair ev;
