@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--shard", choices=["interleave", "frames", "rows"], default="interleave",
                     help="N>1: interleaved 8-row groups + overlapped all-gather (default, bit-identical to one GPU), "
                          "progressive frames round-robin + reduce, or contiguous row bands + all-gather")
+    ap.add_argument("--no-frame1024", action="store_true", help="N=1: skip the measured 1024-spp frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the gather-ceiling probe (rt_debug_probe_walk)")
     ap.add_argument("--rehearse", action="store_true",
@@ -296,6 +297,29 @@ def main():
         r.set_option(R.OPT_RNG_MODE, rng_mode)
         r.reset_accumulation()
 
+    # N=1: the metric's second half, "s/frame at 1024 spp", measured with one launch of 1024 samples per pixel (a warm-up
+    # launch before it sizes the library's buffers) instead of extrapolated from the 256-spp steps
+    frame1024 = None
+    if world == 1 and args.spp != 1024 and not args.no_frame1024:
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1024)
+        r.reset_accumulation()
+        for _ in range(max(settle, 1)):  # a new launch shape: the library's two timed trials first (see `settle`)
+            step()
+        fence()
+        r.reset_accumulation()
+        _ffi._check(L.rt_reset_stats(ctx))
+        tf = time.perf_counter()
+        step()
+        fence()
+        tf = time.perf_counter() - tf
+        sf = _ffi.Stats()
+        _ffi._check(L.rt_get_stats(ctx, C.byref(sf)))
+        frame1024 = {"s_per_frame": tf, "value": sf.rays_traced / tf / 1e6, "unit": "Mrays/s",
+                     "kernel": KERNEL_NAMES.get(sf.last_kernel, "?"), "kernel_ms_per_launch": sf.total_kernel_ms / max(sf.launches, 1),
+                     "note": f"one launch of 1024 spp, same scene / size / depth / rng ({args.rng}); not the bench value"}
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
+        r.reset_accumulation()
+
     # N>1 parity: rank 0 re-renders, on its own, a sample of row groups that OTHER ranks rendered, over all
     # warmup + timed frames, and compares them with the gathered image bit for bit
     parity = None
@@ -443,7 +467,7 @@ def main():
         "kernel_ms_per_launch_by_rank": per_rank_kernel_ms,
         "s_per_frame_1024spp": elapsed_max / args.steps * (1024.0 / (args.spp * (1 if strong or world == 1 else world))),
         "rays_per_step": rays_total / args.steps, "kernel_ms_per_launch": kernel_ms,
-        "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity, "wang_rng": wang, "kernel_choice_launches": settle,
+        "setup_s": setup_s, "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_check": parity, "wang_rng": wang, "frame_1024spp_measured": frame1024, "kernel_choice_launches": settle,
         "commit": git_commit(),
     }
     print(json.dumps(out), flush=True)

@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py > "$OUT/bench_under_rocprof.log" 2>&1
 echo "trace rc=$?"
-bash tools/profile_pmc.sh "$OUT/pmc_pcg" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --no-wang --rng pcg --variant 9   # kernel 9 named: no trial launches
-bash tools/profile_pmc.sh "$OUT/pmc_wang" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --rng wang
+bash tools/profile_pmc.sh "$OUT/pmc_pcg" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --no-wang --no-frame1024 --rng pcg --variant 9   # kernel 9 named: no trial launches
+bash tools/profile_pmc.sh "$OUT/pmc_wang" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --no-frame1024 --rng wang
