@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--shard", choices=["interleave", "frames", "rows"], default="interleave",
                     help="N>1: interleaved 8-row groups + overlapped all-gather (default, bit-identical to one GPU), "
                          "progressive frames round-robin + reduce, or contiguous row bands + all-gather")
-    ap.add_argument("--no-frame1024", action="store_true", help="N=1: skip the measured 1024-spp frame")
+    ap.add_argument("--no-frame1024", action="store_true", help="skip the measured 1024-spp frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the gather-ceiling probe (rt_debug_probe_walk)")
     ap.add_argument("--rehearse", action="store_true",
@@ -297,29 +297,6 @@ def main():
         r.set_option(R.OPT_RNG_MODE, rng_mode)
         r.reset_accumulation()
 
-    # N=1: the metric's second half, "s/frame at 1024 spp", measured with one launch of 1024 samples per pixel (a warm-up
-    # launch before it sizes the library's buffers) instead of extrapolated from the 256-spp steps
-    frame1024 = None
-    if world == 1 and args.spp != 1024 and not args.no_frame1024:
-        r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1024)
-        r.reset_accumulation()
-        for _ in range(max(settle, 1)):  # a new launch shape: the library's two timed trials first (see `settle`)
-            step()
-        fence()
-        r.reset_accumulation()
-        _ffi._check(L.rt_reset_stats(ctx))
-        tf = time.perf_counter()
-        step()
-        fence()
-        tf = time.perf_counter() - tf
-        sf = _ffi.Stats()
-        _ffi._check(L.rt_get_stats(ctx, C.byref(sf)))
-        frame1024 = {"s_per_frame": tf, "value": sf.rays_traced / tf / 1e6, "unit": "Mrays/s",
-                     "kernel": KERNEL_NAMES.get(sf.last_kernel, "?"), "kernel_ms_per_launch": sf.total_kernel_ms / max(sf.launches, 1),
-                     "note": f"one launch of 1024 spp, same scene / size / depth / rng ({args.rng}); not the bench value"}
-        r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
-        r.reset_accumulation()
-
     # N>1 parity: rank 0 re-renders, on its own, a sample of row groups that OTHER ranks rendered, over all
     # warmup + timed frames, and compares them with the gathered image bit for bit
     parity = None
@@ -348,6 +325,38 @@ def main():
         parity = {"pixels": len(rows) * W, "differing": int((a != b).any(-1).sum()), "frames": frames_done,
                   "bar": "gathered N-rank image == rank 0's own render of row groups other ranks rendered, bit-exact"}
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(accum.data_ptr()), W, H))
+
+    # The metric's second half, "s/frame at 1024 spp", measured with one launch of 1024 samples per pixel per rank
+    # (after the library's kernel trials for the new launch shape, which also size its buffers) instead of
+    # extrapolated from the 256-spp steps; all ranks take part, the frame time is the slowest rank's
+    frame1024 = None
+    if mode in ("none", "interleave") and args.spp != 1024 and not args.no_frame1024:
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1024)
+        r.reset_accumulation()
+        for _ in range(max(settle, 1)):
+            step()
+        fence()
+        r.reset_accumulation()
+        _ffi._check(L.rt_reset_stats(ctx))
+        tf = time.perf_counter()
+        step()
+        fence()
+        tf = time.perf_counter() - tf
+        sf = _ffi.Stats()
+        _ffi._check(L.rt_get_stats(ctx, C.byref(sf)))
+        fv = torch.tensor([tf, sf.total_kernel_ms / max(sf.launches, 1), float(sf.rays_traced)], dtype=torch.float64,
+                          device="cpu" if args.rehearse else "cuda")
+        if world > 1:
+            fs = fv.clone()
+            dist.all_reduce(fv, op=dist.ReduceOp.MAX)
+            dist.all_reduce(fs, op=dist.ReduceOp.SUM)
+            fv[2] = fs[2]
+        frame1024 = {"s_per_frame": float(fv[0]), "value": float(fv[2]) / float(fv[0]) / 1e6, "unit": "Mrays/s",
+                     "kernel": KERNEL_NAMES.get(sf.last_kernel, "?"), "kernel_ms_per_launch_slowest_rank": float(fv[1]),
+                     "note": f"one launch of 1024 spp per rank, same scene / size / depth / rng ({args.rng}) / sharding; "
+                             "not the bench value"}
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
+        r.reset_accumulation()
 
     if rank != 0:
         if world > 1:
