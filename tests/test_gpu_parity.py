@@ -536,6 +536,11 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
         _same_image(c.read_accum(w, h), want)
         with pytest.raises(_ffi.RtError, match="PCG"):
             c.render(O.render_params(w, h, 3, 1, 3, rng_mode=T.RNG_WANG))
+        with pytest.raises(_ffi.RtError, match="2\\^28"):  # the depth word's top bits are kernel 9's flags
+            c.render(O.render_params(w, h, 3, 1, 1 << 28, rng_mode=T.RNG_PCG))
+        c.render(O.render_params(w, h, 3, 1, (1 << 28) - 1, rng_mode=T.RNG_PCG))  # the largest depth it takes
+        O.render(sc, cam, O.render_params(w, h, 3, 1, (1 << 28) - 1, rng_mode=T.RNG_PCG), want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
     finally:
         c.close()
 
