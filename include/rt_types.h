@@ -200,6 +200,14 @@ typedef struct rt_render_params {
  * random number; flag set: both operands are evaluated (as a compiler that flattens the condition would), so every
  * dielectric hit advances the RNG once. */
 #define RT_RENDER_DIELECTRIC_ALWAYS_DRAWS 1u
+/* RT_RENDER_SKY_WHITE_HORIZON: the sky of the REVISION THAT RENDERED the reference's Screenshot3.png.  The shader in
+ * the tree blends float3(0.7) -> (0.5, 0.7, 1.0) (RayTracing.slang:162); the screenshot's sky pixels — (224, 237, 255)
+ * at the top row, (235, 244, 255) at the bottom, through the old PNG writer's 256 * clamp(sqrt(c), 0, 0.999) — are those
+ * of float3(1.0) -> (0.5, 0.7, 1.0) to the level (derivation in DESIGN.md §2).  Flag set: the horizon colour is
+ * float3(1.0), the arithmetic is otherwise the same.  Exists so that a render can be compared with that screenshot,
+ * the only output the reference holds (tests/test_reference_screenshot.py). */
+#define RT_RENDER_SKY_WHITE_HORIZON 2u
+#define RT_RENDER_FLAGS_ALL (RT_RENDER_DIELECTRIC_ALWAYS_DRAWS | RT_RENDER_SKY_WHITE_HORIZON)
 
 /* RNG selection (RayTracing.slang:71-72 is RT_RNG_WANG). */
 enum rt_rng_mode {

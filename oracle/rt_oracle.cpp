@@ -1112,7 +1112,9 @@ void shade_pixel(const rt_scene_desc *sc, const rt_camera_uniforms *cam,
         } else { // :159-167
           V3 unit_direction = normalize(r.direction);
           float a = 0.5f * (unit_direction.y + 1.f);
-          V3 sky = v3(0.7f, 0.7f, 0.7f) * (1.f - a) + v3(0.5f, 0.7f, 1.f) * a;
+          // (RT_RENDER_SKY_WHITE_HORIZON: float3(1.0) for float3(0.7) — the revision behind Screenshot3.png, rt_types.h)
+          const float hz = (pc->flags & RT_RENDER_SKY_WHITE_HORIZON) ? 1.0f : 0.7f;
+          V3 sky = v3(hz, hz, hz) * (1.f - a) + v3(0.5f, 0.7f, 1.f) * a;
           sample_radiance = sample_radiance + attenuation * sky;
           break;
         }

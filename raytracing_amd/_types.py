@@ -81,6 +81,7 @@ MATERIAL_LAMBERT, MATERIAL_METAL, MATERIAL_DIELECTRIC, MATERIAL_EMISSIVE, MATERI
 RNG_WANG, RNG_PCG = 0, 1
 AABB_DIV, AABB_RCP = 0, 1
 RENDER_DIELECTRIC_ALWAYS_DRAWS = 1  # rt_render_params.flags
+RENDER_SKY_WHITE_HORIZON = 2
 INVALID_ID = 0xFFFFFFFF
 
 # numpy views of the same layouts (arrays of these are passed by pointer)

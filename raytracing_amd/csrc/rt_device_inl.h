@@ -512,7 +512,8 @@ __device__ __forceinline__ bool shade(const rt_dev_scene &sc, uint32_t flags, bo
   if (!hit_anything) { // :159-167
     V3 unit = normalize(p.d);
     float a = 0.5f * (unit.y + 1.f);
-    V3 sky = v3(0.7f, 0.7f, 0.7f) * (1.f - a) + v3(0.5f, 0.7f, 1.f) * a;
+    const float hz = (flags & RT_RENDER_SKY_WHITE_HORIZON) ? 1.0f : 0.7f; // rt_types.h: the sky behind Screenshot3.png
+    V3 sky = v3(hz, hz, hz) * (1.f - a) + v3(0.5f, 0.7f, 1.f) * a;
     p.sample_radiance = p.sample_radiance + p.attenuation * sky;
     return false;
   }

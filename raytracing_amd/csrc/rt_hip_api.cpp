@@ -595,7 +595,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: no camera set");
   rt_render_params pc = *params;
   if (pc.image_width == 0 || pc.image_height == 0 || pc.sqrt_spp == 0 || pc.sqrt_spp > 4096 ||
-      pc.rng_mode > RT_RNG_PCG || pc.aabb_mode > RT_AABB_RCP || (pc.flags & ~RT_RENDER_DIELECTRIC_ALWAYS_DRAWS))
+      pc.rng_mode > RT_RNG_PCG || pc.aabb_mode > RT_AABB_RCP || (pc.flags & ~RT_RENDER_FLAGS_ALL))
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: bad parameters");
   if (!ctx->accum || ctx->width != pc.image_width || ctx->height != pc.image_height) {
     if (ctx->accum_bound)
