@@ -108,7 +108,11 @@ int rt_reset_stats(rt_ctx *ctx);
  * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
  * depth 3 per launch (the reference's live configuration), and except RT_RNG_PCG launches of at least 2e7 paths (1920x1080 from 10 samples per pixel on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
  * launch of a (scene, launch shape) runs kernel 9, the second kernel 8, both timed (rt_render waits for them), and
- * the following ones the faster of the two.  rt_stats.last_kernel reports the choice.  The kernels
+ * the following ones the faster of the two.  The choice belongs to the uploaded scene and the launch shape:
+ * rt_update_instances keeps it (an animated scene is not re-measured every frame; after 256 updates it is), another
+ * rt_upload_scene, launch shape, wavefront budget or tuning restarts it.  If kernel 9's device memory cannot be
+ * allocated, the automatic choice settles on kernel 8 instead of failing, and when kernel 8 wins the trial kernel 9's
+ * buffers are released.  rt_stats.last_kernel reports the choice.  The kernels
  * that round 1 measured and dropped (numbers 1-7, 10) are in experiments/r01_variants/, outside the library. */
 #define RT_KERNEL_VARIANT_AUTO 0xFFFFFFFFu
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
@@ -133,6 +137,10 @@ int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list
                               uint32_t finish_paths);
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths);
+
+/* Test hook (no counterpart in the reference): the next `count` device allocations for kernel 9's buffers fail as if
+ * the device were out of memory (0 = none). */
+int rt_debug_fail_wavefront_allocs(rt_ctx *ctx, uint32_t count);
 
 /* Measurement aid (no counterpart in the reference): every lane of `blocks`
  * 256-thread workgroups walks the uploaded node records for `steps` dependent,
@@ -159,12 +167,15 @@ int rt_build_tlas_cluster(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, r
                           uint32_t *out_node_count, float *kernel_ms);
 
 /* No counterpart in the reference.  rt_build_tlas_cluster for callers that cannot allocate device memory — a render
- * loop that rebuilds the TLAS every frame, code under HIP graph capture, harnesses that forbid hipMalloc: the same
- * kernel and the same results, with the staged leaves, the output nodes and the node count held in a static device
- * array of the library (384 KiB + 256 B per GPU, resident until the process ends) instead of per-call hipMalloc /
- * hipFree, and no events (no kernel time is reported).  Calls nothing that allocates.  n > RT_TLAS_GPU_MAX_LEAVES is
- * refused with RT_ERR_INVALID_ARGUMENT.  Every context on a GPU shares that GPU's array: calls that overlap on one
- * GPU race (calls of one context are ordered by its stream and the entry point waits before it returns). */
+ * loop that rebuilds the TLAS every frame under a no-allocation rule, serving loops, harnesses that forbid hipMalloc:
+ * the same kernel and the same results, with the staged leaves, the output nodes and the node count held in a static
+ * device array of the library (384 KiB + 256 B per GPU, resident until the process ends) instead of per-call hipMalloc
+ * / hipFree, and no events (no kernel time is reported).  Calls nothing that allocates.  It is NOT capturable into a
+ * HIP graph: it copies from and to the caller's pageable host arrays and waits for the stream before it returns.
+ * n > RT_TLAS_GPU_MAX_LEAVES is refused with RT_ERR_INVALID_ARGUMENT.  Every context on a GPU shares that GPU's array:
+ * calls that overlap on one GPU race (calls of one context are ordered by its stream and the entry point waits before
+ * it returns).  The array's per-device address is looked up by rt_create (hipGetSymbolAddress); contexts created
+ * concurrently from several threads may repeat that lookup — harmless, it yields the same address. */
 int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint32_t n, rt_tlas_node *out_nodes,
                                   uint32_t *out_node_count);
 

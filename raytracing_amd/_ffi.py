@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
@@ -87,6 +87,7 @@ def lib():
     L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
     L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32, u32]
     L.rt_debug_wavefront_counts.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
+    L.rt_debug_fail_wavefront_allocs.argtypes = [vp, u32]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
@@ -220,6 +221,10 @@ class HipContext:
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().rt_debug_wavefront_counts(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
+
+    def fail_wavefront_allocs(self, count):
+        """Test hook: kernel 9's next `count` device allocations fail as if the device were out of memory."""
+        _check(lib().rt_debug_fail_wavefront_allocs(self._h, count))
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))

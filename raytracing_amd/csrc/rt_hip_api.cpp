@@ -118,14 +118,21 @@ struct rt_ctx {
   uint32_t regen_idle = 0;  // persistent kernels: regenerate once this many lanes of a wave are idle; 0 = by scene size
   uint32_t last_kernel = 0; // kernel of the most recent rt_render
   // Automatic choice between kernels 8 and 9 for keyed-PCG launches (rt_render): both are run once on a launch shape
-  // and the faster one keeps it.  `scene_epoch` counts rt_upload_scene / rt_update_instances.
+  // and the faster one keeps it.
   struct Tune {
-    uint32_t key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t phase = 0; // 0 nothing measured, 1 kernel 9 measured, 2 both measured: `choice` holds
     float ms9 = 0.f, ms8 = 0.f;
     uint32_t choice = 9;
+    uint32_t updates = 0; // rt_update_instances calls since the trial
   } tune;
+  // A measured choice belongs to an uploaded scene (`scene_epoch` counts rt_upload_scene) of a certain size (the bit
+  // length of its pair count) and to a launch shape.  rt_update_instances — the reference's per-frame path when objects
+  // move (Renderer.cpp:901-916, 994-1015) — does NOT restart the trial (every frame of an animated scene would then be
+  // a blocking trial launch); it is repeated after RT_TUNE_MAX_UPDATES updates, since the moved instances may have
+  // changed what the rays meet.
   uint32_t scene_epoch = 0;
+  uint32_t fail_allocs = 0; // rt_debug_fail_wavefront_allocs: kernel 9's next device allocations fail (test hook)
   uint32_t pair_count = 0;  // interior records of the uploaded scene (TLAS + every BLAS)
   // timing
   std::vector<EventPair> pending, free_events;
@@ -322,8 +329,107 @@ int upload_pairs_and_instances(rt_ctx *ctx, const rt_blas_instance *instances, u
   ctx->dev.cache_pairs = cached;
   ctx->pair_count = (uint32_t)all.size();
   ctx->wf_geom_dirty = true;
-  ++ctx->scene_epoch; // a measured kernel choice (rt_render) does not carry over
   ctx->dev.flags = moderate ? RT_SCENE_BOXES_MODERATE : 0u;
+  return RT_OK;
+}
+
+// Kernel 9's HBM state for this launch shape: result buffer, path state, the contiguous geometry copy.  Kept for the
+// next launch.  RT_ERR_OUT_OF_MEMORY when the device cannot give it (the caller decides what that means).
+#define RT_TUNE_MAX_UPDATES 256u
+hipError_t wf_reserve(rt_ctx *ctx, DevBuf<uint8_t> &buf, size_t bytes) {
+  if (ctx->fail_allocs && !(buf.ptr && bytes <= buf.count)) { // test hook: this allocation "fails"
+    --ctx->fail_allocs;
+    buf.release();
+    return hipErrorOutOfMemory;
+  }
+  return buf.reserve(bytes);
+}
+
+void release_wavefront(rt_ctx *ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->wf_state.release();
+  ctx->wf_sr.release();
+  ctx->wf_geom.release();
+  ctx->wf = rt_wf_buffers{};
+  ctx->wf_tile_slots = 0;
+  ctx->wf_capacity = 0;
+  ctx->wf_geom_dirty = true;
+}
+
+int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc) {
+  if (pc.rng_mode != RT_RNG_PCG)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
+                                    "state runs through a pixel's samples, so they cannot be traced side by side");
+  if (pc.max_depth >= (1u << 28))
+    return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^28)");
+  // HBM state of the pipeline, sized for this launch shape and kept for the next one
+  const uint32_t rows = rt_virtual_rows(pc);
+  const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
+  const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
+  // paths in flight: a sixth of the chunk's paths (shards of 6.6e7 / 1.3e8 paths, ms per launch with 1/8, 1/7, 1/6,
+  // 1/5, 1/4, 1/3: 38.8 / 38.3 / 37.6 / 37.6 / 38.1 / 37.9 and 69.5 / 68.6 / 68.5 / 69.1 / 70.4 / 71.4; earlier, on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
+  // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
+  // The result buffer first: everything in one chunk if the budget allows, else chunks of whole samples.  If the
+  // device cannot give that much (other tenants), the budget is halved until it can, and stays there.
+  uint64_t chunk_paths;
+  while (true) {
+    chunk_paths = tile_slots * spp;
+    if (chunk_paths * 16 > ctx->wf_sr_bytes)
+      chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
+    if (chunk_paths < tile_slots)
+      chunk_paths = tile_slots; // at least one sample per chunk
+    if (ctx->wf_sr.ptr && ctx->wf.sr_paths >= chunk_paths)
+      break;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const hipError_t ae = wf_reserve(ctx, ctx->wf_sr, (size_t)chunk_paths * 16);
+    ctx->wf.sr = reinterpret_cast<float4 *>(ctx->wf_sr.ptr);
+    ctx->wf.sr_paths = ae == hipSuccess ? chunk_paths : 0;
+    if (ae == hipSuccess)
+      break;
+    (void)hipGetLastError(); // (the failed allocation's sticky error)
+    if (chunk_paths == tile_slots)
+      return fail(RT_ERR_OUT_OF_MEMORY, "rt_render: no device memory for kernel 9's result buffer (one sample per pixel)");
+    ctx->wf_sr_bytes = chunk_paths * 16 / 2;
+  }
+  uint64_t want_slots = (chunk_paths / 6 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
+  if (want_slots < (1u << 20))
+    want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
+  if (want_slots > ctx->wf_slots)
+    want_slots = ctx->wf_slots;
+  if (want_slots < 256)
+    want_slots = 256;
+  if (!ctx->wf_h_ctrl)
+    HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, RT_WF_CTRL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  if (!ctx->wf_state.ptr || ctx->wf_capacity < want_slots || ctx->wf_tile_slots < tile_slots) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;
+    const uint32_t sl = (uint32_t)(want_slots > ctx->wf_capacity ? want_slots : ctx->wf_capacity);
+    const uint32_t pool = rt_wf_pool_records(ctx->cus);
+    ctx->wf_capacity = 0, ctx->wf_tile_slots = 0; // (a failed reallocation leaves nothing behind)
+    HIP_TRY(wf_reserve(ctx, ctx->wf_state, rt_wf_state_bytes(sl, ts, pool)));
+    rt_wf_carve(ctx->wf_state.ptr, sl, ts, pool, ctx->wf);
+    ctx->wf_tile_slots = ts;
+    ctx->wf_capacity = sl;
+  }
+  ctx->wf.slots = (uint32_t)want_slots; // this launch's share of the allocation
+  if (ctx->wf_geom_dirty || !ctx->wf_geom.ptr) {
+    // the trace kernel's cooperative fetch addresses pair records and triangles as 32-bit offsets from one base
+    const size_t pair_bytes = ((size_t)ctx->pair_count * sizeof(rt_dev_pair) + 255) & ~(size_t)255;
+    const size_t tri_bytes = ctx->tris.count * sizeof(rt_dev_tri);
+    if (pair_bytes + tri_bytes + 256 >= (1ull << 32))
+      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 addresses node records and triangles with 32-bit offsets "
+                                      "(scene too large)");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(wf_reserve(ctx, ctx->wf_geom, pair_bytes + tri_bytes + 64));
+    if (ctx->pair_count)
+      HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr, ctx->pairs.ptr, (size_t)ctx->pair_count * sizeof(rt_dev_pair),
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr + pair_bytes, ctx->tris.ptr, tri_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->wf_geom_desc.base = ctx->wf_geom.ptr;
+    ctx->wf_geom_desc.pairs_off = 0;
+    ctx->wf_geom_desc.tris_off = (uint32_t)pair_bytes;
+    ctx->wf_geom_dirty = false;
+  }
   return RT_OK;
 }
 
@@ -469,6 +575,7 @@ int rt_upload_scene(rt_ctx *ctx, const rt_scene_desc *sc) {
   ctx->flat.tris.clear();
   ctx->flat.tris.shrink_to_fit(); // resident in HBM now
   ctx->have_scene = true;
+  ++ctx->scene_epoch; // a measured kernel choice (rt_render) does not carry over to another scene
   return RT_OK;
 }
 
@@ -508,6 +615,7 @@ int rt_update_instances(rt_ctx *ctx, const rt_blas_instance *instances, uint32_t
   if (rc != RT_OK)
     return rc;
   ctx->have_scene = true;
+  ++ctx->tune.updates;
   return RT_OK;
 }
 
@@ -639,11 +747,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
       variant = 0u;
     else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 20000000ull) {
-      const uint32_t key[9] = {ctx->scene_epoch, pc.image_width, pc.image_height, pc.sqrt_spp, pc.max_depth,
-                               pc.row_begin,     pc.row_end,     pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
-      if (memcmp(key, ctx->tune.key, sizeof key) != 0) {
+      uint32_t size_class = 0; // bit length of the pair count: instance edits keep it, another scene rarely does
+      for (uint32_t n = ctx->pair_count; n; n >>= 1)
+        ++size_class;
+      const uint32_t key[10] = {ctx->scene_epoch, size_class,  pc.image_width, pc.image_height,      pc.sqrt_spp,
+                                pc.max_depth,     pc.row_begin, pc.row_end,    pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
+      if (memcmp(key, ctx->tune.key, sizeof key) != 0 || ctx->tune.updates >= RT_TUNE_MAX_UPDATES) {
         memcpy(ctx->tune.key, key, sizeof key);
         ctx->tune.phase = 0;
+        ctx->tune.updates = 0;
       }
       if (ctx->tune.phase == 0)
         variant = tuning = 9u;
@@ -654,79 +766,18 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
     } else
       variant = 8u;
   }
-  const bool wavefront = (variant & 0xFFu) == 9u;
+  bool wavefront = (variant & 0xFFu) == 9u;
   if (wavefront) {
-    if (pc.rng_mode != RT_RNG_PCG)
-      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
-                                      "state runs through a pixel's samples, so they cannot be traced side by side");
-    if (pc.max_depth >= (1u << 28))
-      return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^28)");
-    // HBM state of the pipeline, sized for this launch shape and kept for the next one
-    const uint32_t rows = rt_virtual_rows(pc);
-    const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
-    const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
-    // paths in flight: a sixth of the chunk's paths (shards of 6.6e7 / 1.3e8 paths, ms per launch with 1/8, 1/7, 1/6,
-    // 1/5, 1/4, 1/3: 38.8 / 38.3 / 37.6 / 37.6 / 38.1 / 37.9 and 69.5 / 68.6 / 68.5 / 69.1 / 70.4 / 71.4; earlier, on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
-    // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
-    // The result buffer first: everything in one chunk if the budget allows, else chunks of whole samples.  If the
-    // device cannot give that much (other tenants), the budget is halved until it can, and stays there.
-    uint64_t chunk_paths;
-    while (true) {
-      chunk_paths = tile_slots * spp;
-      if (chunk_paths * 16 > ctx->wf_sr_bytes)
-        chunk_paths = ctx->wf_sr_bytes / 16 / tile_slots * tile_slots;
-      if (chunk_paths < tile_slots)
-        chunk_paths = tile_slots; // at least one sample per chunk
-      if (ctx->wf_sr.ptr && ctx->wf.sr_paths >= chunk_paths)
-        break;
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      const hipError_t ae = ctx->wf_sr.reserve((size_t)chunk_paths * 16);
-      ctx->wf.sr = reinterpret_cast<float4 *>(ctx->wf_sr.ptr);
-      ctx->wf.sr_paths = ae == hipSuccess ? chunk_paths : 0;
-      if (ae == hipSuccess)
-        break;
-      (void)hipGetLastError(); // (the failed allocation's sticky error)
-      if (chunk_paths == tile_slots)
-        return fail(RT_ERR_OUT_OF_MEMORY, "rt_render: no device memory for kernel 9's result buffer (one sample per pixel)");
-      ctx->wf_sr_bytes = chunk_paths * 16 / 2;
-    }
-    uint64_t want_slots = (chunk_paths / 6 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
-    if (want_slots < (1u << 20))
-      want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
-    if (want_slots > ctx->wf_slots)
-      want_slots = ctx->wf_slots;
-    if (want_slots < 256)
-      want_slots = 256;
-    if (!ctx->wf_h_ctrl)
-      HIP_TRY(hipHostMalloc((void **)&ctx->wf_h_ctrl, RT_WF_CTRL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    if (!ctx->wf_state.ptr || ctx->wf_capacity < want_slots || ctx->wf_tile_slots < tile_slots) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      const uint64_t ts = tile_slots > ctx->wf_tile_slots ? tile_slots : ctx->wf_tile_slots;
-      const uint32_t sl = (uint32_t)(want_slots > ctx->wf_capacity ? want_slots : ctx->wf_capacity);
-      const uint32_t pool = rt_wf_pool_records(ctx->cus);
-      HIP_TRY(ctx->wf_state.reserve(rt_wf_state_bytes(sl, ts, pool)));
-      rt_wf_carve(ctx->wf_state.ptr, sl, ts, pool, ctx->wf);
-      ctx->wf_tile_slots = ts;
-      ctx->wf_capacity = sl;
-    }
-    ctx->wf.slots = (uint32_t)want_slots; // this launch's share of the allocation
-    if (ctx->wf_geom_dirty || !ctx->wf_geom.ptr) {
-      // the trace kernel's cooperative fetch addresses pair records and triangles as 32-bit offsets from one base
-      const size_t pair_bytes = ((size_t)ctx->pair_count * sizeof(rt_dev_pair) + 255) & ~(size_t)255;
-      const size_t tri_bytes = ctx->tris.count * sizeof(rt_dev_tri);
-      if (pair_bytes + tri_bytes + 256 >= (1ull << 32))
-        return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 addresses node records and triangles with 32-bit offsets "
-                                        "(scene too large)");
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(ctx->wf_geom.reserve(pair_bytes + tri_bytes + 64));
-      if (ctx->pair_count)
-        HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr, ctx->pairs.ptr, (size_t)ctx->pair_count * sizeof(rt_dev_pair),
-                               hipMemcpyDeviceToDevice, ctx->stream));
-      HIP_TRY(hipMemcpyAsync(ctx->wf_geom.ptr + pair_bytes, ctx->tris.ptr, tri_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-      ctx->wf_geom_desc.base = ctx->wf_geom.ptr;
-      ctx->wf_geom_desc.pairs_off = 0;
-      ctx->wf_geom_desc.tris_off = (uint32_t)pair_bytes;
-      ctx->wf_geom_dirty = false;
+    const int prc = prepare_wavefront(ctx, pc);
+    if (prc != RT_OK) {
+      // Automatic choice: a kernel 9 that cannot have its memory (other tenants on the GPU, a tiny budget) is simply
+      // not eligible — kernel 8 renders the same image with none of it.  A caller that NAMED kernel 9 gets the error.
+      if (!ctx->variant_auto || prc != RT_ERR_OUT_OF_MEMORY)
+        return prc;
+      (void)hipGetLastError();
+      release_wavefront(ctx);
+      ctx->tune.phase = 2, ctx->tune.choice = 8u, ctx->tune.ms9 = ctx->tune.ms8 = 0.f;
+      variant = 8u, tuning = 0u, wavefront = false;
     }
   }
   EventPair ev;
@@ -755,6 +806,8 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       ctx->tune.ms8 = (float)ctx->last_ms;
       ctx->tune.choice = ctx->tune.ms9 <= ctx->tune.ms8 ? 9u : 8u;
       ctx->tune.phase = 2;
+      if (ctx->tune.choice == 8u) // kernel 9 lost: its gigabytes of path state go back to the device
+        release_wavefront(ctx);
     }
   }
   return rc;
@@ -1018,6 +1071,8 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
   ctx->wf_sr.release();
   ctx->wf = rt_wf_buffers{};
   ctx->wf_tile_slots = 0;
+  ctx->wf_capacity = 0;
+  ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old budget
   return RT_OK;
 }
 
@@ -1042,6 +1097,13 @@ int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint3
   if (count == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: instance boxes are not finite");
   *out_node_count = count;
+  return RT_OK;
+}
+
+int rt_debug_fail_wavefront_allocs(rt_ctx *ctx, uint32_t count) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_fail_wavefront_allocs: NULL context");
+  ctx->fail_allocs = count;
   return RT_OK;
 }
 

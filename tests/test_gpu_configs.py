@@ -248,3 +248,98 @@ def test_c3_fixed_ray_sets_a_million_camera_and_a_million_secondary_rays():
         assert (want["tri_id"] != T.INVALID_ID).mean() > 0.2, bounce
     assert total - w * h > 1_000_000  # secondary rays
     r.shutdown()
+
+
+def _oracle_rows(r, cam, w, h, sqrt_spp, depth, rng_mode, stride):
+    """Rows of the 8-row groups 0, stride, 2 * stride, ... rendered by the oracle: (row indices, image)."""
+    sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
+    want = np.zeros((h, w, 4), np.float32)
+    O.render(sa, camu, O.render_params(w, h, 0, sqrt_spp, depth, rng_mode=rng_mode, row_begin=0, row_end=h,
+                                       row_group_stride=stride), want, nthreads=16)
+    return sharding.interleaved_rows(0, stride, h), want
+
+
+def test_c3_kernel9_at_the_bench_shape_equals_the_oracle():
+    """The kernel and launch shape bench.py times — C3, keyed PCG, kernel 9, 1920x1080, 256 spp in ONE launch, default
+    wavefront budget (64 Mi slots, suspension, live-slot list, finishing kernel) — against the oracle at the same
+    256 spp on three 8-row groups (top, middle, bottom); then the north star's 1024-spp frame as one launch (one
+    sample chunk) against the oracle on one 8-row group.  Sample order and sum order per pixel are what
+    RayTracing.slang:76-90, 170-179 prescribe and k_wf_resolve re-creates."""
+    import bench
+    w, h, depth = 1920, 1080, 8
+    r = R.Renderer(w, h, device=0)
+    cam, _ = bench.build_dragon_scene(R, r)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    for spp, stride in ((256, 67), (1024, 200)):
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, spp)
+        got = _launch(r, cam, 9)
+        assert _last_kernel(r) == 9
+        rows, want = _oracle_rows(r, cam, w, h, int(spp ** 0.5), depth, T.RNG_PCG, stride)
+        assert len(rows) == (24 if spp == 256 else 8)
+        assert _same(got[rows], want[rows]), spp
+    rounds, list_rounds, suspended, finished = _ffi_counts(r)
+    assert rounds > 0 and suspended > 0 and finished > 0  # the round scheduling of the timed configuration ran
+    r.shutdown()
+
+
+def _ffi_counts(r):
+    a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _ffi._check(_ffi.lib().rt_debug_wavefront_counts(C.c_void_p(r.hip_context_handle()), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
+
+
+def test_automatic_choice_survives_instance_updates():
+    """The reference's per-frame path when objects move: set_blas_instance_transform -> TLAS rebuild -> render
+    (SceneGraph.cpp:544-566, Renderer.cpp:901-916, 994-1015).  Six launches with an instance moved before each: the
+    first two are the timed trials of kernels 9 and 8, the others run the winner — rt_update_instances does not
+    restart the measurement — and every image equals the oracle's of the scene as it then stands."""
+    w, h, depth, sqrt_spp = 1920, 1080, 8, 4
+    r = R.Renderer(w, h, device=0)
+    cam, _ = r.load_scene_file(os.path.join(SCENES, "teapot.json"))
+    mirror = r.add_metal_material((0.8, 0.85, 0.9), 0.05)
+    cube = r.add_blas_instance(r.cube_blas_index, R.trs((2.0, 0.5, 0.0)), mirror)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, sqrt_spp * sqrt_spp)  # 3.3e7 paths: eligible for kernel 9
+    r.set_option(R.OPT_KERNEL_VARIANT, _ffi.KERNEL_VARIANT_AUTO)
+    kernels = []
+    for k in range(6):
+        r.set_blas_instance_transform(cube, R.trs((2.0 - 0.5 * k, 0.5 + 0.1 * k, 0.3 * k), 0.2 * k, (0, 1, 0), (1, 1 + 0.1 * k, 1)))
+        r.render(cam)
+        got = r.read_image()
+        kernels.append(_last_kernel(r))
+        assert r.frame_index == 1  # the moved instance reset the accumulation (Renderer.cpp:491-494, 1014)
+        rows, want = _oracle_rows(r, cam, w, h, sqrt_spp, depth, T.RNG_PCG, 67)
+        assert _same(got[rows], want[rows]), k
+    assert kernels[:2] == [9, 8] and kernels[2] in (8, 9) and kernels[2:] == [kernels[2]] * 4, kernels
+    r.shutdown()
+
+
+def test_kernel9_without_memory_falls_back_to_kernel8_in_automatic_mode():
+    """kernel 9 wants gigabytes; when the device cannot give them (simulated: the hook makes its
+    allocations fail) the automatic choice renders with kernel 8 instead of failing, and stays there; a caller that
+    NAMED kernel 9 gets RT_ERR_OUT_OF_MEMORY; with memory back, kernel 9 renders the same bits."""
+    w, h = 1920, 1080
+    r = R.Renderer(w, h, device=0)
+    cam, _ = r.load_scene_file(os.path.join(SCENES, "teapot.json"))
+    r.set_option(R.OPT_MAX_DEPTH, 8)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 16)
+    ctx = C.c_void_p(r.hip_context_handle())
+    L = _ffi.lib()
+    want = _launch(r, cam, 8)
+    _ffi._check(L.rt_debug_fail_wavefront_allocs(ctx, 1000))
+    a = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
+    assert _last_kernel(r) == 8 and _same(a, want)
+    b = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)          # settled: no second trial of kernel 9
+    assert _last_kernel(r) == 8 and _same(b, want)
+    r.set_option(R.OPT_KERNEL_VARIANT, 9)
+    r.reset_accumulation()
+    with pytest.raises(R.RendererError, match="memory"):
+        r.render(cam)
+    _ffi._check(L.rt_debug_fail_wavefront_allocs(ctx, 0))
+    _ffi._check(L.rt_set_wavefront_budget(ctx, 1 << 22, 256 << 20))  # (the failures had halved the budget away)
+    c = _launch(r, cam, 9)
+    assert _last_kernel(r) == 9 and _same(c, want)
+    r.shutdown()
