@@ -275,25 +275,38 @@ def main():
     else:
         elapsed_max, rays_total = elapsed, rays_local
 
-    # N=1, PCG: the same workload with the reference's own RNG (sequential Wang hash: megakernel only), same timing rules
+    # N=1, PCG: the same number of samples per pixel with the reference's own RNG (sequential Wang hash), in the
+    # reference's own way — progressive frames of ONE sample per pixel (Renderer.cpp:21, 625; RayTracing.slang:71-72,
+    # 176-179) — handed over as one batch (rt_render_frames: the (pixel, frame) pairs run side by side through the
+    # wavefront pipeline), same timing rules; beside it the single frame of args.spp stratified samples, which the
+    # sequential state confines to the megakernel
     wang = None
     if world == 1 and args.rng == "pcg" and not args.no_wang:
+        def timed(fn, settle_n):
+            r.reset_accumulation()
+            for _ in range(settle_n + args.warmup):
+                fn()
+            fence()
+            r.reset_accumulation()
+            _ffi._check(L.rt_reset_stats(ctx))
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            fence()
+            t = time.perf_counter() - t
+            sw = _ffi.Stats()
+            _ffi._check(L.rt_get_stats(ctx, C.byref(sw)))
+            return {"value": sw.rays_traced / t / 1e6, "unit": "Mrays/s", "ms_per_step": t / args.steps * 1e3,
+                    "kernel": KERNEL_NAMES.get(sw.last_kernel, "?"), "kernel_ms_per_launch": sw.total_kernel_ms / max(sw.launches, 1)}
         r.set_option(R.OPT_RNG_MODE, T.RNG_WANG)
-        r.reset_accumulation()
-        for _ in range(args.warmup):
-            step()
-        fence()
-        _ffi._check(L.rt_reset_stats(ctx))
-        tw = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        tw = time.perf_counter() - tw
-        sw = _ffi.Stats()
-        _ffi._check(L.rt_get_stats(ctx, C.byref(sw)))
-        wang = {"value": sw.rays_traced / tw / 1e6, "unit": "Mrays/s", "ms_per_step": tw / args.steps * 1e3,
-                "kernel": KERNEL_NAMES.get(sw.last_kernel, "?"), "kernel_ms_per_launch": sw.total_kernel_ms / max(sw.launches, 1),
-                "note": "same scene, size, spp and depth with rng_mode = RT_RNG_WANG (Random.slang:7-19)"}
+        single = timed(step, 0)
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1)
+        wang = timed(lambda: r.render_frames(cam, args.spp), 2 if args.variant == _ffi.KERNEL_VARIANT_AUTO else 0)
+        wang["note"] = (f"same scene, size and depth with rng_mode = RT_RNG_WANG (Random.slang:7-19): a step = {args.spp} progressive "
+                        "frames of 1 sample per pixel (the reference's own sampling, Renderer.cpp:21) in one rt_render_frames call")
+        single["note"] = f"one frame of {args.spp} stratified samples per pixel, Wang RNG: one launch of the megakernel"
+        wang["single_frame"] = single
+        r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
         r.set_option(R.OPT_RNG_MODE, rng_mode)
         r.reset_accumulation()
 

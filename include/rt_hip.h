@@ -83,6 +83,15 @@ int rt_clear_accum(rt_ctx *ctx);
 /* replaces push constants + vkCmdDispatch, src/Renderer.cpp:619-648:
  * one launch of the path-tracing megakernel (compute_main). */
 int rt_render(rt_ctx *ctx, const rt_render_params *params);
+/* replaces `frame_count` iterations of the reference's frame loop with an unchanged scene and camera —
+ * PathTracer::run calls Renderer::render once per displayed frame (src/PathTracer.cpp:396-411), each a dispatch of
+ * sqrt_spp^2 (= 1, Renderer.cpp:21, 625) samples per pixel re-seeded by frame_index (RayTracing.slang:71-72) and folded
+ * into the running mean (:176-179; ++frame_index, Renderer.cpp:651).  Frames params->frame_index + k are accumulated
+ * as params->accum_count + k, k = 0 .. frame_count - 1: the image is that of frame_count successive rt_render calls,
+ * bit for bit.  Handing the frames over together lets the library run them side by side: (pixel, frame) pairs are
+ * independent also under the reference's sequential Wang RNG, so batches of at least 2e7 of them may go through the
+ * wavefront pipeline (kernel 9) — which a single frame of the reference's RNG cannot. */
+int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame_count);
 
 /* Test hook: intersect_tlas (TLAS.slang:14-67) over an explicit ray batch.
  * Host-pointer form copies in and out and waits; device form is async. */
@@ -101,12 +110,14 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Low byte: 0 = reference-structured kernel (one lane per pixel, nested sample / bounce / traversal loops);
  * 8 = persistent wave64s with path regeneration, a resumable per-lane traversal, vote scheduling and joined
  * pair / leaf steps (the default); 9 = sample-parallel wavefront pipeline (rt_wavefront.hip: trace, shade and
- * resolve kernels over millions of path slots in HBM), only for RT_RNG_PCG — with the reference's sequential Wang
- * RNG a pixel's samples cannot run side by side, and rt_render refuses kernel 9 (RT_ERR_UNSUPPORTED); rt_render
- * blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
+ * resolve kernels over millions of path slots in HBM): its units of work are the samples of a pixel under RT_RNG_PCG
+ * and the FRAMES of a pixel (rt_render_frames) under the reference's sequential Wang RNG, whose samples within a frame
+ * run one after the other in a slot; rt_render blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
  * rt_launch_render).  All kernels give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new
  * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
- * depth 3 per launch (the reference's live configuration), and except RT_RNG_PCG launches of at least 2e7 paths (1920x1080 from 10 samples per pixel on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
+ * depth 3 per launch (the reference's live configuration), and except launches of at least 2e7 independent units of
+ * work — pixels x frames x samples under RT_RNG_PCG (1920x1080 from 10 samples per pixel on), pixels x frames under
+ * RT_RNG_WANG (rt_render_frames from 10 frames on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
  * launch of a (scene, launch shape) runs kernel 9, the second kernel 8, both timed (rt_render waits for them), and
  * the following ones the faster of the two.  The choice belongs to the uploaded scene and the launch shape:
  * rt_update_instances keeps it (an animated scene is not re-measured every frame; after 256 updates it is), another

@@ -49,6 +49,9 @@ int rth_create(int device_id, uint32_t width, uint32_t height, rth_renderer **ou
 void rth_destroy(rth_renderer *r);
 int rth_resize(rth_renderer *r, uint32_t width, uint32_t height);
 int rth_render(rth_renderer *r, rth_camera *camera);
+/* `frames` iterations of the reference's frame loop (PathTracer.cpp:396-411) in one call: same image and frame index as
+ * `frames` successive rth_render calls (rt_render_frames) */
+int rth_render_frames(rth_renderer *r, rth_camera *camera, uint32_t frames);
 int rth_set_option(rth_renderer *r, int option, uint32_t value);
 uint32_t rth_get_frame_index(rth_renderer *r);
 void rth_reset_accumulation(rth_renderer *r); /* frame_index = 0 */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "librt_hip.so")
 # every symbol include/rt_hip.h declares
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
-    "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_trace_closest",
+    "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_render_frames", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
     "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
@@ -72,6 +72,7 @@ def lib():
     L.rt_bind_accum.argtypes = [vp, vp, u32, u32]
     L.rt_clear_accum.argtypes = [vp]
     L.rt_render.argtypes = [vp, C.POINTER(T.RenderParams)]
+    L.rt_render_frames.argtypes = [vp, C.POINTER(T.RenderParams), u32]
     L.rt_trace_closest.argtypes = [vp, vp, u64, vp, u32]
     L.rt_trace_closest_device.argtypes = [vp, vp, u64, vp, u32]
     L.rt_read_accum.argtypes = [vp, vp]
@@ -174,6 +175,9 @@ class HipContext:
 
     def render(self, params):
         _check(lib().rt_render(self._h, C.byref(params)))
+
+    def render_frames(self, params, frame_count):
+        _check(lib().rt_render_frames(self._h, C.byref(params), frame_count))
 
     def trace_closest(self, rays, aabb_mode=T.AABB_DIV):
         rays = np.ascontiguousarray(rays, T.ray_dtype)

@@ -70,6 +70,15 @@ int rth_render(rth_renderer *r, rth_camera *camera) {
   return rc;
 }
 
+int rth_render_frames(rth_renderer *r, rth_camera *camera, uint32_t frames) {
+  if (!r || !camera)
+    return RT_ERR_INVALID_ARGUMENT;
+  rta::Camera cam = to_camera(camera);
+  int rc = r->r.render_frames(cam, frames);
+  camera->changed = cam.changed ? 1 : 0;
+  return rc;
+}
+
 int rth_set_option(rth_renderer *r, int option, uint32_t value) {
   if (!r)
     return RT_ERR_INVALID_ARGUMENT;

@@ -513,7 +513,14 @@ rt_camera_uniforms Renderer::camera_uniforms(Camera &camera) const {
 }
 
 // Renderer::render, Renderer.cpp:488-652
-int Renderer::render(Camera &camera) {
+int Renderer::render(Camera &camera) { return render_frames(camera, 1u); }
+
+// `frames` iterations of the reference's frame loop (PathTracer.cpp:396-411: render(cam) once per displayed frame) with
+// the scene and camera as they are now, handed to the device in one call (rt_render_frames): the image and
+// frame_index afterwards are those of `frames` successive render() calls.
+int Renderer::render_frames(Camera &camera, uint32_t frames) {
+  if (frames == 0)
+    return RT_OK;
   if (camera.changed) {
     frame_index = 0;
     camera.changed = false;
@@ -542,11 +549,23 @@ int Renderer::render(Camera &camera) {
   pc.rng_mode = rng_mode, pc.aabb_mode = aabb_mode;
   pc.row_begin = row_begin, pc.row_end = row_end, pc.row_group_stride = row_group_stride;
   pc.flags = render_flags;
-  if ((rc = rt_render(ctx_, &pc)) != RT_OK) {
-    last_error_ = rt_last_error_string();
-    return rc;
+  if (frame_stride == 1) {
+    if ((rc = rt_render_frames(ctx_, &pc, frames)) != RT_OK) {
+      last_error_ = rt_last_error_string();
+      return rc;
+    }
+    frame_index += frames;
+    return RT_OK;
   }
-  ++frame_index;
+  for (uint32_t k = 0; k < frames; ++k) { // frames dealt round-robin to several GPUs are not consecutive: one by one
+    pc.frame_index = frame_offset + frame_index * frame_stride;
+    pc.accum_count = frame_index;
+    if ((rc = rt_render(ctx_, &pc)) != RT_OK) {
+      last_error_ = rt_last_error_string();
+      return rc;
+    }
+    ++frame_index;
+  }
   return RT_OK;
 }
 

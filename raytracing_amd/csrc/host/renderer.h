@@ -67,6 +67,7 @@ public:
   void shutdown();
   int resize(uint32_t output_image_width, uint32_t output_image_height);
   int render(Camera &camera);
+  int render_frames(Camera &camera, uint32_t frames); // `frames` successive render() calls in one device call
 
   rt_material_handle add_lambert_material(vec3 albedo);
   rt_material_handle add_lambert_material(int32_t width, int32_t height, const uint8_t *pixels);

@@ -199,8 +199,13 @@ __device__ __forceinline__ bool fast_axis_ok_rcp(float o, float inv) {
 __device__ __forceinline__ f2v div2_exact(f2v n, float d, float r) {
   const f2v nd = {-d, -d}, rr = {r, r};
   const f2v q0 = n * rr;
+#ifdef RT_EXPERIMENT_APPROX_DIV // TIMING EXPERIMENT ONLY (not bit-exact): the upper bound of what a filtered slab test could save
+  (void)nd;
+  return q0;
+#else
   const f2v e0 = __builtin_elementwise_fma(nd, q0, n);
   return __builtin_elementwise_fma(e0, rr, q0);
+#endif
 }
 // Per ray space (world, or an instance's object space): the reciprocals the slab
 // test uses and whether slab_pair_fast may be used.  DIV: inv = refined

@@ -356,16 +356,15 @@ void release_wavefront(rt_ctx *ctx) {
   ctx->wf_geom_dirty = true;
 }
 
-int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc) {
-  if (pc.rng_mode != RT_RNG_PCG)
-    return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 (wavefront pipeline) needs RT_RNG_PCG: the reference's Wang "
-                                    "state runs through a pixel's samples, so they cannot be traced side by side");
+int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc, uint32_t frame_count) {
   if (pc.max_depth >= (1u << 28))
     return fail(RT_ERR_UNSUPPORTED, "rt_render: kernel 9 keeps flags in the top bits of the bounce counter (max_depth < 2^28)");
   // HBM state of the pipeline, sized for this launch shape and kept for the next one
   const uint32_t rows = rt_virtual_rows(pc);
   const uint64_t tile_slots = (uint64_t)((pc.image_width + 7u) >> 3) * ((rows + 7u) >> 3) * 64u;
-  const uint64_t spp = (uint64_t)pc.sqrt_spp * pc.sqrt_spp;
+  const uint64_t spp = rt_wf_entries(pc, frame_count); // entries of work per pixel (rt_wavefront.hip)
+  if (spp > 0xFFFFFFFFull)
+    return fail(RT_ERR_UNSUPPORTED, "rt_render_frames: more than 2^32 samples per pixel in one launch");
   // paths in flight: a sixth of the chunk's paths (shards of 6.6e7 / 1.3e8 paths, ms per launch with 1/8, 1/7, 1/6,
   // 1/5, 1/4, 1/3: 38.8 / 38.3 / 37.6 / 37.6 / 38.1 / 37.9 and 69.5 / 68.6 / 68.5 / 69.1 / 70.4 / 71.4; earlier, on C3 at 1080p: 64 spp = 1.3e8 paths: 16 Mi slots
   // 3960, 32 Mi 3940, 64 Mi 3730 Mrays/s; 256 spp = 5.3e8 paths: 32 Mi 4510, 64 Mi 4580), at most the budget
@@ -694,9 +693,14 @@ static uint32_t effective_regen_idle(const rt_ctx *ctx, const rt_render_params &
   return pc.sqrt_spp * pc.sqrt_spp <= 16u ? 48u : 32u;
 }
 
-int rt_render(rt_ctx *ctx, const rt_render_params *params) {
+int rt_render(rt_ctx *ctx, const rt_render_params *params) { return rt_render_frames(ctx, params, 1u); }
+
+int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame_count) {
   if (!ctx || !params)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: NULL argument");
+  if (frame_count == 0 || frame_count > (1u << 24) || params->frame_index + frame_count < params->frame_index ||
+      params->accum_count + frame_count < params->accum_count)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_frames: 1 .. 2^24 frames, frame and accumulation counters must not wrap");
   if (!ctx->have_scene)
     return fail(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
   if (!ctx->have_camera)
@@ -743,15 +747,18 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
   uint32_t tuning = 0; // 9 / 8: this launch is the timed trial of that kernel
   if (ctx->variant_auto) {
     const uint64_t px = (uint64_t)pc.image_width * (pc.row_end - pc.row_begin) / (pc.row_group_stride > 1u ? pc.row_group_stride : 1u);
-    const uint64_t paths = px * pc.sqrt_spp * pc.sqrt_spp;
-    if (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u)
+    // independent units of work the pipeline can keep in flight: samples (keyed PCG) or frames (Wang) per pixel
+    const uint64_t paths = px * rt_wf_entries(pc, frame_count);
+    // the kernel that renders frame by frame: the megakernel, or the plain one for the reference's live configuration
+    const uint32_t per_frame = (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
+    if (per_frame == 0u && frame_count == 1u)
       variant = 0u;
-    else if (pc.rng_mode == RT_RNG_PCG && pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 20000000ull) {
+    else if (pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 20000000ull) {
       uint32_t size_class = 0; // bit length of the pair count: instance edits keep it, another scene rarely does
       for (uint32_t n = ctx->pair_count; n; n >>= 1)
         ++size_class;
-      const uint32_t key[10] = {ctx->scene_epoch, size_class,  pc.image_width, pc.image_height,      pc.sqrt_spp,
-                                pc.max_depth,     pc.row_begin, pc.row_end,    pc.row_group_stride, pc.aabb_mode | (pc.flags << 8)};
+      const uint32_t key[10] = {ctx->scene_epoch, size_class,  pc.image_width, pc.image_height,      pc.sqrt_spp | (frame_count << 8),
+                                pc.max_depth,     pc.row_begin, pc.row_end,    pc.row_group_stride, pc.aabb_mode | (pc.rng_mode << 4) | (pc.flags << 8)};
       if (memcmp(key, ctx->tune.key, sizeof key) != 0 || ctx->tune.updates >= RT_TUNE_MAX_UPDATES) {
         memcpy(ctx->tune.key, key, sizeof key);
         ctx->tune.phase = 0;
@@ -760,15 +767,15 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       if (ctx->tune.phase == 0)
         variant = tuning = 9u;
       else if (ctx->tune.phase == 1)
-        variant = tuning = 8u;
+        variant = per_frame, tuning = 8u;
       else
-        variant = ctx->tune.choice;
+        variant = ctx->tune.choice == 9u ? 9u : per_frame;
     } else
-      variant = 8u;
+      variant = per_frame;
   }
   bool wavefront = (variant & 0xFFu) == 9u;
   if (wavefront) {
-    const int prc = prepare_wavefront(ctx, pc);
+    const int prc = prepare_wavefront(ctx, pc, frame_count);
     if (prc != RT_OK) {
       // Automatic choice: a kernel 9 that cannot have its memory (other tenants on the GPU, a tiny budget) is simply
       // not eligible — kernel 8 renders the same image with none of it.  A caller that NAMED kernel 9 gets the error.
@@ -777,20 +784,28 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params) {
       (void)hipGetLastError();
       release_wavefront(ctx);
       ctx->tune.phase = 2, ctx->tune.choice = 8u, ctx->tune.ms9 = ctx->tune.ms8 = 0.f;
-      variant = 8u, tuning = 0u, wavefront = false;
+      variant = (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u, tuning = 0u, wavefront = false;
     }
   }
   EventPair ev;
   int rc = begin_timed(ctx, ev);
   if (rc != RT_OK)
     return rc;
-  const hipError_t le =
-      wavefront ? rt_launch_render_wavefront(ctx->dev, ctx->wf_geom_desc, ctx->camera, pc, ctx->accum, ctx->counter.ptr,
-                                             ctx->wf, ctx->wf_h_ctrl, variant | (ctx->variant_auto ? 0u : ctx->regen_idle << 8),
-                                             ctx->wf_tuning, &ctx->wf_counts, ctx->cus, ctx->stream) // bits 8-15: kernel 9's own knobs
-                : rt_launch_render(variant, ctx->dev, ctx->camera, pc, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
-                                   effective_regen_idle(ctx, pc), ctx->cus, ctx->stream);
-  if (le != hipSuccess) { // nothing was launched: the event pair goes back to the pool, `pending` stays consistent
+  hipError_t le = hipSuccess;
+  if (wavefront) { // bits 8-15: kernel 9's own knobs
+    le = rt_launch_render_wavefront(ctx->dev, ctx->wf_geom_desc, ctx->camera, pc, frame_count, ctx->accum, ctx->counter.ptr,
+                                    ctx->wf, ctx->wf_h_ctrl, variant | (ctx->variant_auto ? 0u : ctx->regen_idle << 8),
+                                    ctx->wf_tuning, &ctx->wf_counts, ctx->cus, ctx->stream);
+  } else { // frame by frame, as the reference's loop does (PathTracer.cpp:396-411)
+    rt_render_params pf = pc;
+    for (uint32_t k = 0; k < frame_count && le == hipSuccess; ++k) {
+      pf.frame_index = pc.frame_index + k, pf.accum_count = pc.accum_count + k;
+      le = rt_launch_render(variant, ctx->dev, ctx->camera, pf, ctx->accum, ctx->counter.ptr, ctx->queue.ptr,
+                            effective_regen_idle(ctx, pf), ctx->cus, ctx->stream);
+    }
+  }
+  if (le != hipSuccess) { // the event pair goes back to the pool, `pending` stays consistent
+    (void)hipStreamSynchronize(ctx->stream); // (frames of a batch that were launched before the failure)
     ctx->free_events.push_back(ev);
     return fail(RT_ERR_HIP, std::string("rt_render: launch failed: ") + hipGetErrorString(le));
   }

@@ -17,6 +17,8 @@ struct rt_wf_buffers {
   float4 *rad;        // [slots] sample_radiance.xyz
   float4 *hit;        // [slots] t, triangle id (bits; RT_INVALID_ID = miss), instance id (bits), u
   float *hit_v;       // [slots] v
+  uint32_t *seed;     // [slots] Wang RNG: the pixel's sequential state between two bounces (Random.slang:7-14)
+  float4 *fsum;       // [slots] Wang RNG, spp > 1: the frame's radiance over the samples done so far, sample index (bits)
   uint32_t *ctrl;     // [RT_WF_CTRL_WORDS] striped counters, see rt_wavefront.hip
   uint32_t *block_pos; // [slots / 256] every shade workgroup's position in its share of the chunk's path ids
   float4 *partial;    // [tile slots] radiance summed over the sample chunks done so far
@@ -56,10 +58,13 @@ struct rt_wf_counts { // statistics, summed over launches
   uint64_t finished_paths = 0; // paths alive when k_wf_finish took over
 };
 
-// One rt_render launch through the pipeline.  d_counter: two words, rays traced and rays suspended.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks the host until the
-// image is complete (the host reads the list lengths back between rounds).  pc.rng_mode must be RT_RNG_PCG.
+// `frame_count` consecutive frames (pc.frame_index + k accumulated as pc.accum_count + k) through the pipeline.
+// d_counter: two words, rays traced and rays suspended.  h_ctrl: pinned host memory, RT_WF_CTRL_WORDS uint32.  Blocks
+// the host until the image is complete (the host reads the list lengths back between rounds).
+// Entries of work (rt_wavefront.hip): frame_count * spp for RT_RNG_PCG, frame_count for RT_RNG_WANG.
+uint64_t rt_wf_entries(const rt_render_params &pc, uint32_t frame_count);
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
-                                      const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
+                                      const rt_render_params &pc, uint32_t frame_count, float *d_accum, unsigned long long *d_counter,
                                       const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, const rt_wf_tuning &tune,
                                       rt_wf_counts *counts, uint32_t cus, hipStream_t stream);
 

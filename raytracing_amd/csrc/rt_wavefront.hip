@@ -22,6 +22,18 @@
 // is coalesced, and every round traces about `slots` rays until the chunk runs out.
 // Per pixel the arithmetic, the RNG keys and the order of the radiance sum are those of k_render_v0 in PCG mode, so
 // the image is the same bit for bit.
+//
+// Round 3: FRAME BATCHES and the reference's own RNG.  The reference reaches high sample counts by progressive frames
+// of sqrt_spp^2 (= 1) samples each, re-seeding the Wang state per (x, y, frame_index) (RayTracing.slang:71-72,
+// Renderer.cpp:21, 625, 651): the samples of ONE frame of a pixel are a sequence, but (pixel, frame) pairs are
+// independent.  rt_render_frames hands a launch `frame_count` consecutive frames, and the unit of work in a slot — an
+// ENTRY — is
+//   keyed PCG:  (pixel, frame, sample): every sample independent, as before; entry j = frame * spp + sample
+//   Wang:       (pixel, frame): the frame's samples run one after the other IN the slot, the Wang state (4 B per slot)
+//               carried from bounce to bounce and from sample to sample, the frame's radiance summed in sample order
+//               in the slot (16 B per slot, touched when a sample ends, only if spp > 1); entry j = frame
+// k_wf_resolve then walks a pixel's entries in order, closes a frame every `per_frame` entries and applies the running
+// mean (RayTracing.slang:174-179) frame by frame — the same operations in the same order as frame_count launches.
 #include "rt_device_inl.h"
 #include "rt_wavefront.h"
 
@@ -68,22 +80,28 @@ __host__ __device__ inline uint32_t wf_alive_set(uint32_t pass) { return (pass &
 #define WF_REC_STACK (WF_REC_WORDS - 8u)    // deepest stack a record holds; a wave with a deeper one does not suspend
 
 struct WfChunk {
-  uint32_t s0;       // first sample of the chunk
-  uint32_t cs;       // samples in the chunk
+  uint32_t s0;       // first entry of the chunk (entries count through the launch's frames, see the file comment)
+  uint32_t cs;       // entries in the chunk
   uint32_t tiles_x;  // 8x8 tiles per (virtual) row of tiles
   uint32_t total;    // path ids of the chunk: tiles * cs * 64
   uint32_t slots;    // path slots in use for this chunk
   uint32_t slot_span; // slots per band of the trace kernel's queue (a multiple of 64)
   uint32_t list_span; // entries per stripe of the live-slot list: the slots of the shade workgroups of one stripe
+  uint32_t per_frame; // entries per frame: spp (keyed PCG) or 1 (Wang)
 };
 
 __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const WfChunk &ch, uint32_t id, uint32_t &x,
-                                            uint32_t &y, uint32_t &sample) {
-  const uint32_t in = id & 63u, ts = id >> 6; // ts = tile * cs + sample_in_chunk
+                                            uint32_t &y, uint32_t &entry) {
+  const uint32_t in = id & 63u, ts = id >> 6; // ts = tile * cs + entry_in_chunk
   const uint32_t tile = ts / ch.cs;
-  sample = ch.s0 + (ts - tile * ch.cs);
+  entry = ch.s0 + (ts - tile * ch.cs);
   x = (tile % ch.tiles_x) * 8u + (in & 7u);
   y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
+}
+
+// Seed of the reference's RNG for frame `frame` of the launch (RayTracing.slang:71-72 with frame_index + frame).
+__device__ __forceinline__ uint32_t wf_wang_seed(const rt_render_params &pc, uint32_t x, uint32_t y, uint32_t frame) {
+  return (x * 1973u) ^ (y * 9277u) ^ ((pc.frame_index + frame) * 26699u);
 }
 
 // Starts new paths in the slots of the lanes with want == true.  No global atomics (same-line atomics run at about
@@ -94,6 +112,7 @@ __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const Wf
 // workgroup's position in its share lives in b.block_pos[blockIdx], touched by one thread per round.  Ids on tile
 // padding outside the image are skipped (the lane draws again).  Returns true for lanes that wrote a camera ray.
 // Must be called by all threads of the workgroup.
+template <bool WANG>
 __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, const rt_render_params &pc,
                                               const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot) {
   __shared__ uint32_t s_cnt[RT_BLOCK / 64], s_base;
@@ -127,14 +146,23 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
         want = false; // the workgroup's share is used up (later positions lie even further out)
       } else {
         const uint32_t id = (uint32_t)id64;
-        uint32_t x, y, sample;
-        wf_pixel_of(pc, ch, id, x, y, sample);
+        uint32_t x, y, entry;
+        wf_pixel_of(pc, ch, id, x, y, entry);
         if (x < pc.image_width && y < pc.row_end) { // else tile padding: draw another id
           Rng rng = make_rng(pc, x, y);
-          rng.sample = pc.frame_index * spp + sample;
-          rng.set_slot(0);
           Path p;
-          camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          if (WANG) { // entry = frame: its first sample; the state goes on through the frame's bounces and samples
+            rng.seed = wf_wang_seed(pc, x, y, entry);
+            camera_ray(cam, recip_sqrt_spp, x, y, 0u, 0u, rng, p);
+            b.seed[slot] = rng.seed;
+            if (spp > 1u)
+              b.fsum[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+          } else {      // entry = frame * spp + sample: the absolute sample index keys the draws
+            const uint32_t sample = entry % spp;
+            rng.sample = pc.frame_index * spp + entry;
+            rng.set_slot(0);
+            camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          }
           b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
           b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
           want = false; // (attenuation 1 and sample radiance +0: WF_HAS_ATT / WF_HAS_RAD clear, nothing to store)
@@ -152,7 +180,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
 // every slot is refilled the moment its path ends, so all slots stay busy; only the last rounds thin out).  All state
 // traffic is coalesced.  INIT: nothing to shade, every slot just starts a path (the first fill of a chunk).
 // ---------------------------------------------------------------------------
-template <bool INIT>
+template <bool INIT, bool WANG>
 __global__ void __launch_bounds__(RT_BLOCK)
     k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t pass) {
   const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -172,11 +200,15 @@ __global__ void __launch_bounds__(RT_BLOCK)
       const float4 at = has_att ? b.att[slot] : make_float4(1.f, 1.f, 1.f, 0.f);
       const float4 ra = has_rad ? b.rad[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t id = __float_as_uint(ro.w);
-      uint32_t x, y, sample;
-      wf_pixel_of(pc, ch, id, x, y, sample);
+      uint32_t x, y, entry;
+      wf_pixel_of(pc, ch, id, x, y, entry);
       Rng rng = make_rng(pc, x, y);
-      rng.sample = pc.frame_index * (pc.sqrt_spp * pc.sqrt_spp) + sample;
-      rng.set_slot(depth + 1u);
+      if (WANG) {
+        rng.seed = b.seed[slot]; // the pixel's sequential state, where the bounce before left it
+      } else {
+        rng.sample = pc.frame_index * (pc.sqrt_spp * pc.sqrt_spp) + entry;
+        rng.set_slot(depth + 1u);
+      }
       Path p;
       p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
       p.attenuation = v3(at.x, at.y, at.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
@@ -194,14 +226,38 @@ __global__ void __launch_bounds__(RT_BLOCK)
         b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
         if (keep_rad)
           b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        if (WANG)
+          b.seed[slot] = rng.seed;
         goes_on = true;
+      } else if (WANG) { // the sample ended: RayTracing.slang:170 in the slot, then the frame's next sample or its end
+        const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+        V3 sum = v3(0.f, 0.f, 0.f);
+        uint32_t s_idx = 0;
+        if (spp > 1u) {
+          const float4 fs = b.fsum[slot];
+          sum = v3(fs.x, fs.y, fs.z), s_idx = __float_as_uint(fs.w);
+        }
+        sum = sum + p.sample_radiance;
+        if (s_idx + 1u < spp) { // the next sample of this pixel and frame continues the RNG stream (:76-77)
+          ++s_idx;
+          Path np;
+          camera_ray(cam, 1.f / (float)pc.sqrt_spp, x, y, s_idx % pc.sqrt_spp, s_idx / pc.sqrt_spp, rng, np);
+          b.ray_o[slot] = make_float4(np.o.x, np.o.y, np.o.z, ro.w);
+          b.ray_d[slot] = make_float4(np.d.x, np.d.y, np.d.z, __uint_as_float(0u));
+          b.seed[slot] = rng.seed;
+          b.fsum[slot] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx));
+          goes_on = true;
+        } else {
+          b.sr[id] = make_float4(sum.x, sum.y, sum.z, 0.f); // the frame's radiance
+          ended = true;
+        }
       } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
         b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
         ended = true;
       }
     }
   }
-  const bool started = wf_regenerate(cam, pc, ch, b, ended, slot);
+  const bool started = wf_regenerate<WANG>(cam, pc, ch, b, ended, slot);
   if (ended && !started)
     b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
   // Live paths after this pass: one atomic per workgroup on its stripe's counter (the host sums the stripes), and what
@@ -642,6 +698,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
 // workgroup, if that still has ids (the same strided share as wf_regenerate, one id per atomic), so the chunk is
 // complete when the kernel ends whatever was left.  No slot may be suspended (the host checks).
 // ---------------------------------------------------------------------------
+template <bool WANG>
 __global__ void __launch_bounds__(RT_BLOCK)
     k_wf_finish(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t set,
                 uint32_t shade_blocks, unsigned long long *ray_counter) {
@@ -664,20 +721,45 @@ __global__ void __launch_bounds__(RT_BLOCK)
     const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
     const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
     const uint32_t blk = slot / RT_BLOCK; // the shade workgroup that owns the slot, and its share of the ids
-    while (true) {
-      uint32_t x, y, sample;
-      wf_pixel_of(pc, ch, id, x, y, sample);
-      Rng rng = make_rng(pc, x, y);
-      rng.sample = pc.frame_index * spp + sample;
-      for (; depth < pc.max_depth; ++depth) { // (a path in a slot has depth < max_depth)
-        rng.set_slot(depth + 1u);
-        Hit hit;
-        const bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
-        ++traced;
-        if (!shade(sc, pc.flags, any, hit, rng, p))
-          break;
+    // Wang: the pixel's RNG state and the frame's radiance so far travel with the slot
+    uint32_t seed = 0, s_idx = 0;
+    V3 sum = v3(0.f, 0.f, 0.f);
+    if (WANG) {
+      seed = b.seed[slot];
+      if (spp > 1u) {
+        const float4 fs = b.fsum[slot];
+        sum = v3(fs.x, fs.y, fs.z), s_idx = __float_as_uint(fs.w);
       }
-      b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+    }
+    while (true) {
+      uint32_t x, y, entry;
+      wf_pixel_of(pc, ch, id, x, y, entry);
+      Rng rng = make_rng(pc, x, y);
+      if (WANG)
+        rng.seed = seed;
+      else
+        rng.sample = pc.frame_index * spp + entry;
+      while (true) { // (keyed PCG: one sample; Wang: what is left of the frame's samples, one after the other)
+        for (; depth < pc.max_depth; ++depth) { // (a path in a slot has depth < max_depth)
+          rng.set_slot(depth + 1u);
+          Hit hit;
+          const bool any = trace_mode(sc, pc.aabb_mode, p.o, p.d, 0.0001f, 1000.f, hit, st);
+          ++traced;
+          if (!shade(sc, pc.flags, any, hit, rng, p))
+            break;
+        }
+        if (!WANG)
+          break;
+        sum = sum + p.sample_radiance; // RayTracing.slang:170
+        if (++s_idx >= spp)
+          break;
+        camera_ray(cam, recip_sqrt_spp, x, y, s_idx % pc.sqrt_spp, s_idx / pc.sqrt_spp, rng, p);
+        depth = 0;
+      }
+      if (WANG)
+        b.sr[id] = make_float4(sum.x, sum.y, sum.z, 0.f);
+      else
+        b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
       // the next path of the workgroup's share, if any (ids on tile padding are skipped)
       bool started = false;
       while (true) {
@@ -686,12 +768,19 @@ __global__ void __launch_bounds__(RT_BLOCK)
         if (id64 >= ch.total)
           break;
         id = (uint32_t)id64;
-        wf_pixel_of(pc, ch, id, x, y, sample);
+        wf_pixel_of(pc, ch, id, x, y, entry);
         if (x < pc.image_width && y < pc.row_end) {
           rng = make_rng(pc, x, y);
-          rng.sample = pc.frame_index * spp + sample;
-          rng.set_slot(0);
-          camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          if (WANG) {
+            rng.seed = wf_wang_seed(pc, x, y, entry);
+            camera_ray(cam, recip_sqrt_spp, x, y, 0u, 0u, rng, p);
+            seed = rng.seed, s_idx = 0, sum = v3(0.f, 0.f, 0.f);
+          } else {
+            const uint32_t sample = entry % spp;
+            rng.sample = pc.frame_index * spp + entry;
+            rng.set_slot(0);
+            camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+          }
           depth = 0;
           started = true;
           break;
@@ -720,19 +809,35 @@ __global__ void __launch_bounds__(RT_BLOCK)
   const uint32_t y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
   if (!(x < pc.image_width && y < pc.row_end))
     return;
-  V3 radiance = v3(0.f, 0.f, 0.f);
+  V3 radiance = v3(0.f, 0.f, 0.f); // of the frame that is open at the chunk's first entry
   if (!first) {
     const float4 part = b.partial[i];
     radiance = v3(part.x, part.y, part.z);
   }
   const float4 *sr = b.sr + ((size_t)tile * ch.cs) * 64u + in;
+  float4 *px = accum + ((size_t)y * pc.image_width + x);
+  const float pixel_sample_scale = 1.f / (float)(pc.sqrt_spp * pc.sqrt_spp);
+  V3 acc = v3(0.f, 0.f, 0.f);
+  bool have_acc = false; // the pixel's running mean is read when its first frame of this chunk closes
+  uint32_t in_frame = ch.s0 % ch.per_frame, frame = ch.s0 / ch.per_frame;
   for (uint32_t s = 0; s < ch.cs; ++s) {
     const float4 v = sr[(size_t)s * 64u];
     radiance = radiance + v3(v.x, v.y, v.z);
+    if (++in_frame == ch.per_frame) { // the frame is complete: RayTracing.slang:174-179 with frame_index + frame
+      if (!have_acc) {
+        const float4 prev = *px;
+        acc = v3(prev.x, prev.y, prev.z), have_acc = true;
+      }
+      const uint32_t count = pc.accum_count + frame;
+      const float fi = (float)count, fi1 = (float)(count + 1u);
+      acc = (acc * fi + radiance * pixel_sample_scale) / fi1;
+      radiance = v3(0.f, 0.f, 0.f);
+      in_frame = 0, ++frame;
+    }
   }
-  if (last)
-    accumulate(accum, pc.image_width, x, y, radiance, pc.sqrt_spp, pc.accum_count);
-  else
+  if (have_acc)
+    *px = make_float4(acc.x, acc.y, acc.z, 1.f);
+  if (!last)
     b.partial[i] = make_float4(radiance.x, radiance.y, radiance.z, 0.f);
 }
 
@@ -750,7 +855,7 @@ uint32_t rt_wf_pool_records(uint32_t cus) { // one record per lane of every trac
 }
 
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records) {
-  return (size_t)slots * (5 * sizeof(float4) + sizeof(float)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) +
+  return (size_t)slots * (6 * sizeof(float4) + sizeof(float) + sizeof(uint32_t)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) + 2 * 256 +
          ((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t) + ((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t) +
          (size_t)2 * pool_records * WF_REC_WORDS * sizeof(uint32_t) +
          (size_t)tile_slots * sizeof(float4) + 16 * 256;
@@ -771,6 +876,8 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
   b.rad = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.hit = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.hit_v = reinterpret_cast<float *>(take((size_t)slots * sizeof(float)));
+  b.seed = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
+  b.fsum = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
   b.block_pos = reinterpret_cast<uint32_t *>(take(((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t)));
   b.live = reinterpret_cast<uint32_t *>(take(((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t)));
@@ -784,19 +891,25 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
 #define RT_WF_COOP_MINW 5
 #define RT_WF_COOP_NLDS 12
 
+uint64_t rt_wf_entries(const rt_render_params &pc, uint32_t frame_count) {
+  return pc.rng_mode == RT_RNG_WANG ? (uint64_t)frame_count : (uint64_t)frame_count * pc.sqrt_spp * pc.sqrt_spp;
+}
+
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
-                                      const rt_render_params &pc, float *d_accum, unsigned long long *d_counter,
+                                      const rt_render_params &pc, uint32_t frame_count, float *d_accum, unsigned long long *d_counter,
                                       const rt_wf_buffers &b, uint32_t *h_ctrl, uint32_t knobs, const rt_wf_tuning &tune,
                                       rt_wf_counts *counts, uint32_t cus, hipStream_t stream) {
   const uint32_t rows = rt_virtual_rows(pc);
-  if (rows == 0 || pc.image_width == 0)
+  if (rows == 0 || pc.image_width == 0 || frame_count == 0)
     return hipSuccess;
-  if (cus == 0 || b.slots < 64 || pc.rng_mode != RT_RNG_PCG || pc.max_depth >= WF_SUSPENDED)
+  const bool wang = pc.rng_mode == RT_RNG_WANG;
+  const uint64_t entries = rt_wf_entries(pc, frame_count);
+  if (cus == 0 || b.slots < 64 || pc.rng_mode > RT_RNG_PCG || pc.max_depth >= WF_SUSPENDED || entries > 0xFFFFFFFFull)
     return hipErrorInvalidValue;
   const uint32_t tiles_x = (pc.image_width + 7u) >> 3;
   const uint64_t tile_slots = (uint64_t)tiles_x * ((rows + 7u) >> 3) * 64u;
-  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
-  uint64_t chunk = b.sr_paths / tile_slots; // samples whose results fit the result buffer
+  const uint32_t spp = (uint32_t)entries; // entries of the launch: the loop below hands them out in chunks
+  uint64_t chunk = b.sr_paths / tile_slots; // entries whose results fit the result buffer
   if (chunk > spp)
     chunk = spp;
   if (chunk != 0 && tile_slots * chunk > 0xF0000000ull) // path ids are 32-bit
@@ -844,6 +957,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       ch.slots = b.slots / 64u * 64u;
     ch.slot_span = span64(ch.slots);
     ch.list_span = ((ch.slots + RT_BLOCK - 1) / RT_BLOCK + WF_STRIPES - 1) / WF_STRIPES * RT_BLOCK;
+    ch.per_frame = wang ? 1u : pc.sqrt_spp * pc.sqrt_spp;
     const bool first = s0 == 0, last = s0 + ch.cs == spp;
     if (pc.max_depth == 0) { // no bounce is traced: every sample contributes nothing (RayTracing.slang:92)
       if ((e = hipMemsetAsync(b.sr, 0, (size_t)ch.total * sizeof(float4), stream)) != hipSuccess)
@@ -855,7 +969,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
-      hipLaunchKernelGGL((k_wf_shade<true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+      if (wang)
+        hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+      else
+        hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
       bool have_list = false; // the last shade pass wrote the live-slot list
       bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
       for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
@@ -876,8 +993,12 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
           uint32_t longest = 0;
           for (uint32_t k = 0; k < WF_STRIPES; ++k)
             longest = h_ctrl[k * WF_PAD] > longest ? h_ctrl[k * WF_PAD] : longest;
-          hipLaunchKernelGGL(k_wf_finish, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream, sc, cam,
-                             pc, b, ch, round, shade_blocks, d_counter);
+          if (wang)
+            hipLaunchKernelGGL(k_wf_finish<true>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
+                               sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+          else
+            hipLaunchKernelGGL(k_wf_finish<false>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
+                               sc, cam, pc, b, ch, round, shade_blocks, d_counter);
           if ((e = hipGetLastError()) != hipSuccess)
             return e;
           if (counts)
@@ -908,8 +1029,12 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
           RT_WF_TRACE(RT_AABB_RCP);
         else
           RT_WF_TRACE(RT_AABB_DIV);
-        hipLaunchKernelGGL((k_wf_shade<false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
-                           (round + 1u) | (make_list ? 0x80000000u : 0u));
+        if (wang)
+          hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                             (round + 1u) | (make_list ? 0x80000000u : 0u));
+        else
+          hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                             (round + 1u) | (make_list ? 0x80000000u : 0u));
         have_list = make_list;
         if ((e = hipGetLastError()) != hipSuccess)
           return e;

@@ -24,7 +24,7 @@ OPT_RENDER_FLAGS = 11
 PLANE, CUBE, SPHERE = 0, 1, 2
 
 HOST_SYMBOLS = [
-    "rth_create", "rth_destroy", "rth_resize", "rth_render", "rth_set_option", "rth_get_frame_index",
+    "rth_create", "rth_destroy", "rth_resize", "rth_render", "rth_render_frames", "rth_set_option", "rth_get_frame_index",
     "rth_reset_accumulation", "rth_add_lambert_material", "rth_add_lambert_texture", "rth_add_lambert_image",
     "rth_decode_image", "rth_write_png_rgb8", "rth_import_gltf",
     "rth_add_metal_material", "rth_add_dielectric_material", "rth_add_emissive_material",
@@ -67,6 +67,7 @@ def lib():
     L.rth_destroy.argtypes = [vp]; L.rth_destroy.restype = None
     L.rth_resize.argtypes = [vp, u32, u32]
     L.rth_render.argtypes = [vp, C.POINTER(CameraC)]
+    L.rth_render_frames.argtypes = [vp, C.POINTER(CameraC), u32]
     L.rth_set_option.argtypes = [vp, C.c_int, u32]
     L.rth_get_frame_index.argtypes = [vp]; L.rth_get_frame_index.restype = u32
     L.rth_reset_accumulation.argtypes = [vp]; L.rth_reset_accumulation.restype = None
@@ -264,6 +265,10 @@ class Renderer:
 
     def render(self, camera):
         self._ok(lib().rth_render(self._h, C.byref(camera.c)))
+
+    def render_frames(self, camera, frames):
+        """`frames` progressive frames (the reference's frame loop, PathTracer.cpp:396-411) in one device call."""
+        self._ok(lib().rth_render_frames(self._h, C.byref(camera.c), frames))
 
     def add_lambert_material(self, albedo):
         return lib().rth_add_lambert_material(self._h, T.ptr(_f32(albedo)))
