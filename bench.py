@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--aabb", choices=["div", "rcp"], default="div")
     ap.add_argument("--rng", choices=["wang", "pcg"], default="pcg")
+    ap.add_argument("--progressive", action="store_true",
+                    help="a step = --spp progressive frames of ONE sample per pixel in one rt_render_frames call (the reference's own "
+                         "sampling, Renderer.cpp:21) instead of one frame of --spp stratified samples")
     ap.add_argument("--no-wang", action="store_true", help="N=1, --rng pcg: skip the extra measurement with the reference's RNG")
     ap.add_argument("--defocus", action="store_true", help="the C5 camera: thin lens instead of the pinhole")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0xFFFFFFFF,
@@ -172,7 +175,7 @@ def main():
     t_setup = time.time()
     r = R.Renderer(W, H, device=local_rank)
     cam, n_tris = build_dragon_scene(R, r, defocus=args.defocus)
-    r.set_option(R.OPT_SAMPLES_PER_PIXEL, args.spp)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1 if args.progressive else args.spp)
     r.set_option(R.OPT_MAX_DEPTH, args.depth)
     r.set_option(R.OPT_AABB_MODE, aabb_mode)
     r.set_option(R.OPT_RNG_MODE, rng_mode)
@@ -211,7 +214,10 @@ def main():
     setup_s = time.time() - t_setup
 
     def step():
-        r.render(cam)          # one launch: args.spp samples for every pixel of this rank's rows
+        if args.progressive:
+            r.render_frames(cam, args.spp)  # args.spp frames of one sample per pixel, one call
+        else:
+            r.render(cam)      # one launch: args.spp samples for every pixel of this rank's rows
         if mode == "interleave":
             with torch.cuda.stream(s_render):
                 k = gather.step & 1
@@ -241,7 +247,7 @@ def main():
 
     # With no kernel named, the library times kernel 9 and kernel 8 once each on a new keyed-PCG launch shape and keeps
     # the faster (rt_hip.h, rt_set_kernel_variant): two launches of set-up, like the BVH build, before the warmup
-    settle = 2 if (args.rng == "pcg" and args.variant == _ffi.KERNEL_VARIANT_AUTO) else 0
+    settle = 2 if ((args.rng == "pcg" or args.progressive) and args.variant == _ffi.KERNEL_VARIANT_AUTO) else 0
     for _ in range(settle):
         step()
     fence()
@@ -281,7 +287,7 @@ def main():
     # wavefront pipeline), same timing rules; beside it the single frame of args.spp stratified samples, which the
     # sequential state confines to the megakernel
     wang = None
-    if world == 1 and args.rng == "pcg" and not args.no_wang:
+    if world == 1 and args.rng == "pcg" and not args.no_wang and not args.progressive:
         def timed(fn, settle_n):
             r.reset_accumulation()
             for _ in range(settle_n + args.warmup):
@@ -343,7 +349,7 @@ def main():
     # (after the library's kernel trials for the new launch shape, which also size its buffers) instead of
     # extrapolated from the 256-spp steps; all ranks take part, the frame time is the slowest rank's
     frame1024 = None
-    if mode in ("none", "interleave") and args.spp != 1024 and not args.no_frame1024:
+    if mode in ("none", "interleave") and args.spp != 1024 and not args.no_frame1024 and not args.progressive:
         r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1024)
         r.reset_accumulation()
         for _ in range(max(settle, 1)):
@@ -415,7 +421,7 @@ def main():
         bytes_per_ray = trav_b + accum_b / rays_per_sample
         trav_p, accum_p = product_layout_bytes_per_ray(cnd, args.spp)
         product_bytes = trav_p + accum_p / rays_per_sample
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not args.progressive:
         # Parity of THE KERNEL THAT WAS TIMED at THE SHAPE THAT WAS TIMED: frame 0 of the timed configuration (same
         # kernel — named, not left to the automatic choice — same spp per launch, same wavefront budget) rendered again,
         # and three 8-row groups of it (top, middle, bottom: 24 rows x W pixels x spp paths) compared bit for bit with
@@ -456,48 +462,104 @@ def main():
                                      "differing": int((got0.view(np.uint32) != want0.view(np.uint32)).any(-1).sum())}
         _ffi._check(L.rt_bind_accum(ctx, C.c_void_p(accum.data_ptr()), W, H))
     if bytes_per_ray is not None:
-        achieved = bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        # the PMC passes are separate rocprofv3 runs (tools/profile_pmc.sh) taken on the default workload; the figure
-        # is read from their committed summary, not measured in this process: other shapes report none
-        if world == 1 and os.path.exists(tpath) and \
+        # The roofs ("Roofline"): the dominant kernel is the traversal kernel — k_wf_trace of the wavefront
+        # pipeline, or the megakernel.  Its duration is measured HERE with HIP events on the launch stream; the
+        # instruction and byte counts of one launch come from the committed PMC passes of the same workload
+        # (profiles/roofline_latest.json, tools/roofline_from_pmc.py — PMC needs rocprofv3 runs of their own), and
+        # only for that workload.  Every fraction is against a peak of MI355X_MICROARCH.md.
+        VALU_PEAK = 256 * 4 * 2.4 / 2.0   # G wave-instr/s: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 VALU instruction per 2 cycles
+        FABRIC_GATHER_PEAK = 7650.0       # GB/s: random rows of a 151 MB table (Infinity Cache resident), guide "Indexed rows": 7.4-7.9 TB/s
+        algorithmic = bytes_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e9
+        per_kernel = None
+        if world == 1 and kernel_id == 9:
+            ms5, nl = (C.c_double * 5)(), C.c_uint64()
+            _ffi._check(L.rt_debug_wavefront_timing(ctx, 1, None, None))
+            _ffi._check(L.rt_reset_stats(ctx))
+            _ffi._check(L.rt_set_kernel_variant(ctx, 9))
+            for _ in range(2):
+                step()
+            fence()
+            _ffi._check(L.rt_debug_wavefront_timing(ctx, 0, ms5, C.byref(nl)))
+            _ffi._check(L.rt_set_kernel_variant(ctx, args.variant))
+            n = max(nl.value, 1)
+            per_kernel = {"k_wf_trace": ms5[0] / n, "k_wf_shade": ms5[1] / n, "k_wf_finish": ms5[2] / n,
+                          "k_wf_resolve": ms5[3] / n, "first_fill": ms5[4] / n, "launches": nl.value,
+                          "how": "HIP events on the launch stream around every dispatch of two extra launches (rt_debug_wavefront_timing)"}
+        label = args.rng + ("-frames" if args.progressive else "")  # the profile's name for this sampling
+        cdoc, ckey = None, f"{label}:{'k_wf_trace' if kernel_id == 9 else 'k_render_v8'}"
+        cpath = os.path.join(ROOT, "profiles", "roofline_latest.json")
+        if world == 1 and os.path.exists(cpath) and \
                 (W, H, args.spp, args.depth, args.aabb, args.defocus) == (1920, 1080, 256, 8, "div", False):
             try:
-                tdoc = json.load(open(tpath))
-                if tdoc.get("rng", "wang") != args.rng:
-                    raise KeyError("taken with another RNG mode")
-                traffic = tdoc.get("hbm_bytes_per_launch")
-                traffic_source = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                  f"tools/profile_pmc.sh, kernel {tdoc.get('kernel')}, taken at commit "
-                                  f"{tdoc.get('commit', 'unrecorded')}; not measured in this run)")
+                cdoc = json.load(open(cpath))
+                if ckey not in cdoc["kernels"]:
+                    cdoc = None
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": KERNEL_NAMES.get(kernel_id, "?"), "kernel_ms": kernel_ms,
-                    "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
-                    "definition": "SURVEY.md 8(d): bytes counted with the REFERENCE's record sizes for the visits the "
-                                  "oracle counts; most of them are cache hits here (scene resident in the 256 MB "
-                                  "Infinity Cache), so this is not achieved HBM bandwidth — see requested_* and "
-                                  "gather_ceiling for the roofs that bind",
-                    "requested_bytes_per_ray": product_bytes,
-                    "requested_GBps": product_bytes * rays_per_launch / (kernel_ms * 1e-3) / 1e9,
-                    "traffic_frac_of_peak": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None}
+                cdoc = None
+        trace_ms = per_kernel["k_wf_trace"] if per_kernel else kernel_ms
+        roofline = {"kernel": "k_wf_trace" if kernel_id == 9 else KERNEL_NAMES.get(kernel_id, "?"),
+                    "kernel_ms": trace_ms, "launch_ms": kernel_ms, "kernel_ms_by_kernel": per_kernel,
+                    "rays_per_launch": rays_per_launch}
+        if cdoc is not None:
+            k = cdoc["kernels"][ckey]
+            valu = k["valu_wave_insts"] / (trace_ms * 1e-3) / 1e9
+            roofline.update({
+                "bound": "valu", "achieved": valu, "peak": VALU_PEAK, "unit": "G wave-instr/s", "frac": valu / VALU_PEAK,
+                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 VALU instruction issues over 2 cycles",
+                "lane_utilisation": k["lane_utilisation"], "lane_weighted_frac": valu / VALU_PEAK * k["lane_utilisation"],
+                "wait_any_over_wave_cycles": k["wait_any_over_wave_cycles"], "l2_hit_rate": k["l2_hit_rate"],
+                "fabric_gather": {
+                    "what": "L2-miss reads of the traversal kernel (FETCH_SIZE; includes Infinity-Cache hits: the 199 MB scene "
+                            "lives there) against the guide's rate for random rows of a cache-resident table",
+                    "achieved_GBps_raw": k["fetch_bytes_raw"] / (trace_ms * 1e-3) / 1e9,
+                    "achieved_GBps_x2": 2 * k["fetch_bytes_raw"] / (trace_ms * 1e-3) / 1e9,
+                    "peak": FABRIC_GATHER_PEAK, "frac_raw": k["fetch_bytes_raw"] / (trace_ms * 1e-3) / 1e9 / FABRIC_GATHER_PEAK,
+                    "frac_x2": 2 * k["fetch_bytes_raw"] / (trace_ms * 1e-3) / 1e9 / FABRIC_GATHER_PEAK,
+                    "note": "FETCH_SIZE tallies 128-byte requests as 64 (guide, HBM section): raw is exact for 64-byte requests, x2 "
+                            "for wide streams; 16-byte divergent gathers are uncalibrated, the truth lies between"}})
+            # `traffic`: every dispatch of the launch; what these counters are is said beside it
+            tot_fetch = sum(v["fetch_bytes_raw"] for kk, v in cdoc["kernels"].items() if kk.startswith(label + ":") and
+                            (v["kernel"].startswith("k_wf_") if kernel_id == 9 else v["kernel"] == "k_render_v8"))
+            tot_write = sum(v["write_bytes"] for kk, v in cdoc["kernels"].items() if kk.startswith(label + ":") and
+                            (v["kernel"].startswith("k_wf_") if kernel_id == 9 else v["kernel"] == "k_render_v8"))
+            roofline["traffic"] = tot_fetch + tot_write
+            roofline["traffic_is"] = ("L2-miss (fabric-side) bytes of one launch, all its dispatches: FETCH_SIZE raw + WRITE_SIZE. "
+                                      "NOT HBM bytes — Infinity-Cache hits are counted (guide, HBM section)")
+            roofline["counter_source"] = (f"profiles/roofline_latest.json ({k['pmc_dir']}, rocprofv3 --pmc passes of tools/profile_pmc.sh "
+                                          f"on this workload, commit {cdoc.get('commit')}); durations measured in this run")
+            sh = cdoc["kernels"].get(f"{label}:k_wf_shade")
+            if kernel_id == 9 and sh and per_kernel:
+                # the shade pass streams the path state (wide coalesced 16-byte accesses: FETCH_SIZE x2 is the calibrated reading)
+                hb = (2 * sh["fetch_bytes_raw"] + sh["write_bytes"]) / (per_kernel["k_wf_shade"] * 1e-3) / 1e9
+                roofline["secondary"] = {"kernel": "k_wf_shade", "bound": "hbm", "kernel_ms": per_kernel["k_wf_shade"],
+                                         "achieved": hb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBPS,
+                                         "bytes_per_launch": 2 * sh["fetch_bytes_raw"] + sh["write_bytes"],
+                                         "note": "5.9 GB of path state streams through HBM every round; 6.29 TB/s is the guide's measured copy rate"}
+        else:
+            roofline.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                             "note": "no committed PMC counters for this workload / kernel: see gather_probe and algorithmic_GBps"})
+        roofline["algorithmic_bytes_per_ray"] = bytes_per_ray
+        roofline["algorithmic_GBps"] = algorithmic
+        roofline["algorithmic_note"] = ("SURVEY.md 8(d): bytes counted with the REFERENCE's record sizes for the visits the oracle counts, over "
+                                        "the whole launch; most are L1 / L2 / Infinity-Cache hits, so this is no bandwidth of any one level "
+                                        "and carries no fraction")
+        roofline["requested_bytes_per_ray"] = product_bytes
+        roofline["requested_GBps"] = product_bytes * rays_per_launch / (kernel_ms * 1e-3) / 1e9
         if not args.no_probe and world == 1 and cnd is not None:
-            # the roof that binds: dependent divergent 64-B record gathers through L1/L2, measured here
-            # by walking the same node records with no arithmetic at the kernel's occupancy (4 waves per SIMD)
+            # the L1 / texture-path ceiling for this access pattern, measured in this process: dependent divergent 64-B
+            # record gathers over this scene's node records, no arithmetic, at the probe's best occupancy (4 waves per SIMD)
             best = 0.0
             for _ in range(3):
                 ms, steps = C.c_double(), C.c_uint64()
                 _ffi._check(L.rt_debug_probe_walk(ctx, 256 * 4, 2000, 4, C.byref(ms), C.byref(steps)))
                 best = max(best, steps.value / (ms.value * 1e-3))
             visits_per_ray = (cnd["tlas_interior"] + cnd["blas_interior"] + cnd["tlas_leaf"] + cnd["tris_tested"]) / max(cnd["rays"], 1)
-            kernel_rate = visits_per_ray * rays_per_launch / (kernel_ms * 1e-3)
-            roofline["gather_ceiling"] = {"visits_per_s": best, "kernel_visits_per_s": kernel_rate,
-                                          "frac": kernel_rate / best, "record_visits_per_ray": visits_per_ray,
-                                          "how": "rt_debug_probe_walk: 1024 blocks x 256 lanes, 2000 dependent 64-B "
-                                                 "record gathers per lane over this scene's node records, best of 3"}
+            kernel_rate = visits_per_ray * rays_per_launch / (trace_ms * 1e-3)
+            roofline["gather_probe"] = {"visits_per_s": best, "kernel_visits_per_s": kernel_rate,
+                                        "frac": kernel_rate / best, "record_visits_per_ray": visits_per_ray,
+                                        "how": "rt_debug_probe_walk: 1024 blocks x 256 lanes, 2000 dependent 64-B record gathers per "
+                                               "lane over this scene's node records, best of 3; the kernel's visits over the traversal "
+                                               "kernel's own duration.  A measured yardstick of the per-lane gather path, not a guide peak"}
 
     sharding_txt = {"none": "none", "interleave": "interleaved 8-row groups per rank, RCCL all-gather per step overlapped "
                     "with the next launch", "rows": "row bands per rank, RCCL all-gather per step",
@@ -511,6 +573,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL: shared GPU, gloo)",
         "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)" + (", C5 thin-lens camera" if args.defocus else ""),
                    "triangles": n_tris, "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
+                   "sampling": f"{args.spp} progressive frames of 1 spp per step (rt_render_frames)" if args.progressive else f"one frame of {args.spp} stratified spp per step",
                    "rng": args.rng, "aabb": args.aabb, "kernel": KERNEL_NAMES.get(kernel_id, "?"), "sharding": sharding_txt},
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "kernel_ms_per_launch_by_rank": per_rank_kernel_ms,

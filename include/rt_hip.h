@@ -149,6 +149,12 @@ int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths);
 
+/* Measurement aid (no counterpart in the reference): while enabled, every dispatch of a kernel-9 launch is bracketed by
+ * HIP events on the launch stream and the launch waits for them at its end.  Returns (either pointer may be NULL) the
+ * times summed since rt_reset_stats — out_ms5 = k_wf_trace, k_wf_shade, k_wf_finish, k_wf_resolve, first fill, in ms — and
+ * the number of launches they cover, then sets the mode.  bench.py's per-kernel roofline durations come from here. */
+int rt_debug_wavefront_timing(rt_ctx *ctx, int enable, double *out_ms5, uint64_t *out_launches);
+
 /* Test hook (no counterpart in the reference): the next `count` device allocations for kernel 9's buffers fail as if
  * the device were out of memory (0 = none). */
 int rt_debug_fail_wavefront_allocs(rt_ctx *ctx, uint32_t count);
@@ -193,6 +199,45 @@ int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint3
 const char *rt_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only machine; never fails) */
 int rt_device_count(void);
+
+/* ---- several GPUs of one node (no counterpart in the reference, which is single-GPU) ----
+ * One rt_ctx and one host thread per rank, the scene replicated on every GPU.  A frame is cut into groups of 8 rows
+ * dealt round-robin: rank r of n renders groups r, r + n, ... (rt_render_params.row_begin = 8 r, row_group_stride = n;
+ * rt_mgpu_partition is that bookkeeping, callable without a GPU).  After every rt_mgpu_render_frames the row groups are
+ * exchanged ONCE — a direct ncclAllGather of the packed groups over RCCL (xGMI), each rank packing and unpacking on its
+ * own stream behind its launch — so every rank's image is complete and equals the one-GPU image bit for bit (no
+ * floating-point re-association).  RCCL is dlopen'ed on first use.  exchange_mode: AUTO = RCCL when every rank has a
+ * GPU of its own and RCCL loads, else peer copies between the ranks' images (hipMemcpyPeerAsync, host barriers: the
+ * rehearsal of n ranks on fewer GPUs); RCCL = refuse to fall back; COPY = peer copies.
+ * Calls are made from ONE controlling thread; the per-rank work runs on the driver's own threads.  Failures return a
+ * negative rt_status and leave the message in rt_last_error_string() of the calling thread. */
+typedef struct rt_mgpu rt_mgpu;
+typedef struct rt_mgpu_share {
+  uint32_t groups_total;     /* 8-row groups of the image */
+  uint32_t groups;           /* groups this rank renders */
+  uint32_t groups_per_rank;  /* ceil(groups_total / n): the all-gather's equal share (tail = padding) */
+  uint32_t rows;             /* image rows this rank renders */
+  uint32_t row_begin, row_end, row_group_stride; /* the rank's rt_render_params fields */
+} rt_mgpu_share;
+enum { RT_MGPU_EXCHANGE_AUTO = 0, RT_MGPU_EXCHANGE_RCCL = 1, RT_MGPU_EXCHANGE_COPY = 2 };
+int rt_mgpu_partition(uint32_t image_height, uint32_t ranks, uint32_t rank, rt_mgpu_share *out);
+int rt_mgpu_create(const int *device_ids, uint32_t ranks, uint32_t exchange_mode, rt_mgpu **out);
+int rt_mgpu_destroy(rt_mgpu *m);
+uint32_t rt_mgpu_ranks(rt_mgpu *m);
+int rt_mgpu_uses_rccl(rt_mgpu *m);
+rt_ctx *rt_mgpu_context(rt_mgpu *m, uint32_t rank); /* e.g. for rt_set_wavefront_budget; not for launches */
+int rt_mgpu_upload_scene(rt_mgpu *m, const rt_scene_desc *scene);             /* rt_upload_scene on every rank */
+int rt_mgpu_update_instances(rt_mgpu *m, const rt_blas_instance *instances, uint32_t instance_count,
+                             const rt_tlas_node *tlas_nodes, uint32_t tlas_node_count);
+int rt_mgpu_set_camera(rt_mgpu *m, const rt_camera_uniforms *camera);
+int rt_mgpu_set_kernel_variant(rt_mgpu *m, uint32_t variant);
+int rt_mgpu_resize(rt_mgpu *m, uint32_t width, uint32_t height);
+int rt_mgpu_clear_accum(rt_mgpu *m);
+/* rt_render_frames on every rank's share (params' row fields are set per rank), then the exchange; returns when every
+ * rank holds the complete image */
+int rt_mgpu_render_frames(rt_mgpu *m, const rt_render_params *params, uint32_t frame_count);
+int rt_mgpu_read_accum(rt_mgpu *m, uint32_t rank, float *host_rgba32f);
+int rt_mgpu_get_stats(rt_mgpu *m, uint32_t rank, rt_stats *out);
 
 #ifdef __cplusplus
 }

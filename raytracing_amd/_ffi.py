@@ -19,10 +19,13 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_render_frames", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_debug_wavefront_timing", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
+    "rt_mgpu_partition", "rt_mgpu_create", "rt_mgpu_destroy", "rt_mgpu_ranks", "rt_mgpu_uses_rccl", "rt_mgpu_context",
+    "rt_mgpu_upload_scene", "rt_mgpu_update_instances", "rt_mgpu_set_camera", "rt_mgpu_set_kernel_variant", "rt_mgpu_resize",
+    "rt_mgpu_clear_accum", "rt_mgpu_render_frames", "rt_mgpu_read_accum", "rt_mgpu_get_stats",
 ]
 
 
@@ -34,6 +37,14 @@ class Stats(C.Structure):
                 ("total_kernel_ms", C.c_double), ("launches", C.c_uint64),
                 ("stack_depth_needed", C.c_uint32), ("last_kernel", C.c_uint32),
                 ("device_bytes", C.c_uint64)]
+
+
+class MgpuShare(C.Structure):  # rt_mgpu_share
+    _fields_ = [(n, C.c_uint32) for n in ("groups_total", "groups", "groups_per_rank", "rows", "row_begin", "row_end",
+                                          "row_group_stride")]
+
+
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 
 
 class RtError(RuntimeError):
@@ -89,12 +100,28 @@ def lib():
     L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32, u32]
     L.rt_debug_wavefront_counts.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.rt_debug_fail_wavefront_allocs.argtypes = [vp, u32]
+    L.rt_debug_wavefront_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
     L.rt_debug_probe_walk.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rt_last_error_string.restype = C.c_char_p
     L.rt_device_count.restype = C.c_int
     for name in SYMBOLS:
         if name not in ("rt_last_error_string",):
             getattr(L, name).restype = C.c_int
+    L.rt_mgpu_partition.argtypes = [u32, u32, u32, C.POINTER(MgpuShare)]
+    L.rt_mgpu_create.argtypes = [C.POINTER(C.c_int), u32, u32, C.POINTER(vp)]
+    L.rt_mgpu_destroy.argtypes = [vp]
+    L.rt_mgpu_ranks.argtypes = [vp]; L.rt_mgpu_ranks.restype = u32
+    L.rt_mgpu_uses_rccl.argtypes = [vp]
+    L.rt_mgpu_context.argtypes = [vp, u32]; L.rt_mgpu_context.restype = vp
+    L.rt_mgpu_upload_scene.argtypes = [vp, C.POINTER(T.SceneDesc)]
+    L.rt_mgpu_update_instances.argtypes = [vp, vp, u32, vp, u32]
+    L.rt_mgpu_set_camera.argtypes = [vp, C.POINTER(T.CameraUniforms)]
+    L.rt_mgpu_set_kernel_variant.argtypes = [vp, u32]
+    L.rt_mgpu_resize.argtypes = [vp, u32, u32]
+    L.rt_mgpu_clear_accum.argtypes = [vp]
+    L.rt_mgpu_render_frames.argtypes = [vp, C.POINTER(T.RenderParams), u32]
+    L.rt_mgpu_read_accum.argtypes = [vp, u32, vp]
+    L.rt_mgpu_get_stats.argtypes = [vp, u32, C.POINTER(Stats)]
     _LIB = L
     return L
 
@@ -232,3 +259,67 @@ class HipContext:
 
     def set_kernel_variant(self, v):
         _check(lib().rt_set_kernel_variant(self._h, v))
+
+
+def mgpu_partition(height, ranks, rank):
+    """rt_mgpu_partition: the rank's share of an image cut into 8-row groups (no GPU needed)."""
+    sh = MgpuShare()
+    _check(lib().rt_mgpu_partition(height, ranks, rank, C.byref(sh)))
+    return sh
+
+
+class MultiGpu:
+    """rt_mgpu: one rt_ctx and one host thread per rank, interleaved 8-row groups, one image exchange per launch."""
+
+    def __init__(self, devices, exchange_mode=EXCHANGE_AUTO):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().rt_mgpu_create(arr, len(devices), exchange_mode, C.byref(self._h)))
+        self.ranks = len(devices)
+
+    def close(self):
+        if self._h:
+            lib().rt_mgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self):
+        return bool(lib().rt_mgpu_uses_rccl(self._h))
+
+    def upload_scene(self, scene):
+        d = scene.desc()
+        _check(lib().rt_mgpu_upload_scene(self._h, C.byref(d)))
+
+    def update_instances(self, instances, tlas_nodes, tlas_node_count):
+        _check(lib().rt_mgpu_update_instances(self._h, T.ptr(instances), len(instances), T.ptr(tlas_nodes), int(tlas_node_count)))
+
+    def set_camera(self, cam):
+        _check(lib().rt_mgpu_set_camera(self._h, C.byref(cam)))
+
+    def set_kernel_variant(self, v):
+        _check(lib().rt_mgpu_set_kernel_variant(self._h, v))
+
+    def resize(self, w, h):
+        _check(lib().rt_mgpu_resize(self._h, w, h))
+
+    def clear_accum(self):
+        _check(lib().rt_mgpu_clear_accum(self._h))
+
+    def render_frames(self, params, frame_count=1):
+        _check(lib().rt_mgpu_render_frames(self._h, C.byref(params), frame_count))
+
+    def read_accum(self, rank, width, height):
+        out = np.zeros((height, width, 4), np.float32)
+        _check(lib().rt_mgpu_read_accum(self._h, rank, T.ptr(out)))
+        return out
+
+    def stats(self, rank):
+        s = Stats()
+        _check(lib().rt_mgpu_get_stats(self._h, rank, C.byref(s)))
+        return s

@@ -437,6 +437,8 @@ int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc, uint32_t frame_co
 extern "C" {
 
 const char *rt_last_error_string(void) { return g_last_error.c_str(); }
+// (rt_multi.cpp reports through the same channel)
+void rt_internal_set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
 int rt_device_count(void) {
   int n = 0;
@@ -937,7 +939,9 @@ int rt_reset_stats(rt_ctx *ctx) {
   HIP_TRY(hipMemsetAsync(ctx->counter.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
   ctx->total_ms = ctx->last_ms = 0.0;
   ctx->launches = 0;
+  const bool timing = ctx->wf_counts.timing;
   ctx->wf_counts = rt_wf_counts{};
+  ctx->wf_counts.timing = timing;
   return RT_OK;
 }
 
@@ -1112,6 +1116,21 @@ int rt_build_tlas_cluster_noalloc(rt_ctx *ctx, const rt_tlas_node *leaves, uint3
   if (count == 0)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_build_tlas_cluster_noalloc: instance boxes are not finite");
   *out_node_count = count;
+  return RT_OK;
+}
+
+int rt_debug_wavefront_timing(rt_ctx *ctx, int enable, double *out_ms5, uint64_t *out_launches) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_timing: NULL context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (out_ms5) {
+    out_ms5[0] = ctx->wf_counts.trace_ms, out_ms5[1] = ctx->wf_counts.shade_ms, out_ms5[2] = ctx->wf_counts.finish_ms;
+    out_ms5[3] = ctx->wf_counts.resolve_ms, out_ms5[4] = ctx->wf_counts.fill_ms;
+  }
+  if (out_launches)
+    *out_launches = ctx->wf_counts.timed_launches;
+  ctx->wf_counts.timing = enable != 0;
   return RT_OK;
 }
 

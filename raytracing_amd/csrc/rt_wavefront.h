@@ -56,6 +56,11 @@ struct rt_wf_counts { // statistics, summed over launches
   uint64_t rounds = 0;      // trace + shade rounds
   uint64_t list_rounds = 0; // of these, rounds whose trace pass walked the live-slot list
   uint64_t finished_paths = 0; // paths alive when k_wf_finish took over
+  // per-kernel GPU time (HIP events on the launch stream around every dispatch), filled only while `timing` is set
+  // (rt_debug_wavefront_timing: the events and the extra wait at the end of the launch are a measurement mode)
+  bool timing = false;
+  double trace_ms = 0, shade_ms = 0, finish_ms = 0, resolve_ms = 0, fill_ms = 0;
+  uint64_t timed_launches = 0;
 };
 
 // `frame_count` consecutive frames (pc.frame_index + k accumulated as pc.accum_count + k) through the pipeline.

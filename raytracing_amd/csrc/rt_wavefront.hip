@@ -34,6 +34,8 @@
 //               in the slot (16 B per slot, touched when a sample ends, only if spp > 1); entry j = frame
 // k_wf_resolve then walks a pixel's entries in order, closes a frame every `per_frame` entries and applies the running
 // mean (RayTracing.slang:174-179) frame by frame — the same operations in the same order as frame_count launches.
+#include <vector>
+
 #include "rt_device_inl.h"
 #include "rt_wavefront.h"
 
@@ -946,6 +948,42 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
     return (uint32_t)((per + 63) / 64 * 64);
   };
   hipError_t e;
+  // measurement mode: an event before and after every dispatch, read back when the launch has drained
+  struct Stamp {
+    hipEvent_t a, b;
+    double *into;
+  };
+  std::vector<Stamp> stamps;
+  const bool timing = counts && counts->timing;
+  auto stamp_begin = [&](double *into) {
+    if (!timing)
+      return;
+    Stamp st{nullptr, nullptr, into};
+    if (hipEventCreate(&st.a) == hipSuccess && hipEventCreate(&st.b) == hipSuccess && hipEventRecord(st.a, stream) == hipSuccess)
+      stamps.push_back(st);
+  };
+  auto stamp_end = [&]() {
+    if (timing && !stamps.empty())
+      (void)hipEventRecord(stamps.back().b, stream);
+  };
+  struct StampsDone { // runs on every return path
+    std::vector<Stamp> &v;
+    hipStream_t stream;
+    rt_wf_counts *counts;
+    ~StampsDone() {
+      if (v.empty())
+        return;
+      (void)hipStreamSynchronize(stream);
+      for (Stamp &st : v) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, st.a, st.b) == hipSuccess)
+          *st.into += ms;
+        (void)hipEventDestroy(st.a);
+        (void)hipEventDestroy(st.b);
+      }
+      ++counts->timed_launches;
+    }
+  } stamps_done{stamps, stream, counts};
   for (uint32_t s0 = 0; s0 < spp; s0 += (uint32_t)chunk) {
     WfChunk ch;
     ch.s0 = s0;
@@ -969,10 +1007,12 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
+      stamp_begin(counts ? &counts->fill_ms : nullptr);
       if (wang)
         hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
       else
         hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+      stamp_end();
       bool have_list = false; // the last shade pass wrote the live-slot list
       bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
       for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
@@ -993,12 +1033,14 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
           uint32_t longest = 0;
           for (uint32_t k = 0; k < WF_STRIPES; ++k)
             longest = h_ctrl[k * WF_PAD] > longest ? h_ctrl[k * WF_PAD] : longest;
+          stamp_begin(counts ? &counts->finish_ms : nullptr);
           if (wang)
             hipLaunchKernelGGL(k_wf_finish<true>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
                                sc, cam, pc, b, ch, round, shade_blocks, d_counter);
           else
             hipLaunchKernelGGL(k_wf_finish<false>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
                                sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+          stamp_end();
           if ((e = hipGetLastError()) != hipSuccess)
             return e;
           if (counts)
@@ -1025,16 +1067,20 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         // the paths thin out every ray is seen through, or the stragglers would add rounds of their own
         const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * RT_BLOCK <= b.pool_records
                                    ? susp_lanes : 0u) | ((round & 1u) << 8) | (by_list ? 0x200u : 0u) | ((round & 1u) << 10) | (share << 16);
+        stamp_begin(counts ? &counts->trace_ms : nullptr);
         if (pc.aabb_mode == RT_AABB_RCP)
           RT_WF_TRACE(RT_AABB_RCP);
         else
           RT_WF_TRACE(RT_AABB_DIV);
+        stamp_end();
+        stamp_begin(counts ? &counts->shade_ms : nullptr);
         if (wang)
           hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
                              (round + 1u) | (make_list ? 0x80000000u : 0u));
         else
           hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
                              (round + 1u) | (make_list ? 0x80000000u : 0u));
+        stamp_end();
         have_list = make_list;
         if ((e = hipGetLastError()) != hipSuccess)
           return e;
@@ -1045,8 +1091,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         }
       }
     }
+    stamp_begin(counts ? &counts->resolve_ms : nullptr);
     hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,
                        b, ch, (uint32_t)tile_slots, accum, first ? 1u : 0u, last ? 1u : 0u);
+    stamp_end();
     if ((e = hipGetLastError()) != hipSuccess)
       return e;
   }

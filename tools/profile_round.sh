@@ -10,3 +10,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 echo "trace rc=$?"
 bash tools/profile_pmc.sh "$OUT/pmc_pcg" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --no-wang --no-frame1024 --rng pcg --variant 9   # kernel 9 named: no trial launches
 bash tools/profile_pmc.sh "$OUT/pmc_wang" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --no-frame1024 --rng wang
+# the reference's RNG as the reference samples: 256 progressive frames of 1 spp in one batch, through kernel 9 (named: no trials)
+bash tools/profile_pmc.sh "$OUT/pmc_wang_frames" --steps 1 --warmup 0 --no-cpu-baseline --no-probe --rng wang --progressive --variant 9
