@@ -58,6 +58,48 @@ def build_dragon_scene(R, renderer, defocus=False):
     return cam, mesh.triangle_count + 2
 
 
+def build_teapot_dragon_scene(R, renderer):
+    """C3b: a second dragon-class mesh, NON-uniformly tessellated — assets/teapot.obj (1024 triangles whose areas
+    span two orders of magnitude) subdivided 1:4 five times and displaced by seeded noise: 1,048,576 triangles
+    (csrc/host/meshes.h, subdivide_displace) — on the same ground plane under the same sky.  Not the bench workload:
+    it checks that the statistics and the kernel ranking measured on the regular tube are not artefacts of its grid."""
+    import os
+    (tea, _, _), = R.Mesh.load_obj(os.path.join(ROOT, "assets", "teapot.obj"))
+    mesh = tea.subdivided(5, 0.02, 1234)
+    blas = renderer.add_blas(mesh)
+    body = renderer.add_lambert_material((0.62, 0.5, 0.35))
+    ground = renderer.add_lambert_material((0.6, 0.6, 0.6))
+    renderer.add_blas_instance(blas, R.trs((0, 0.55, 0), 0.6, (0, 1, 0), (1.1, 1.1, 1.1)), body)
+    renderer.add_blas_instance(renderer.plane_blas_index, R.trs((0, -0.02, 0), 0.0, (0, 1, 0), (14, 1, 14)), ground)
+    cam = R.Camera((1.9, 1.5, 2.3), (0.0, 0.5, 0.0), (0, 1, 0), 40.0)
+    return cam, mesh.triangle_count + 2
+
+
+def build_instances_scene(R, renderer, n_side=45, seed=7):
+    """C4: n_side^2 transformed instances of teapot / sphere / cube on a jittered grid with random rotations and
+    scales, lambert / metal / dielectric / emissive materials, on a ground plane (2025 instances by default)."""
+    import math
+    import os
+    rng = np.random.default_rng(seed)
+    (tea, _, _), = R.Mesh.load_obj(os.path.join(ROOT, "assets", "teapot.obj"))
+    r = renderer
+    blases = [r.cube_blas_index, r.sphere_blas_index, r.add_blas(tea)]
+    mats = [r.default_material, r.add_lambert_material((0.8, 0.3, 0.2)), r.add_metal_material((0.8, 0.8, 0.9), 0.05),
+            r.add_metal_material((0.9, 0.6, 0.2), 0.4), r.add_dielectric_material(1.5), r.add_emissive_material((4.0, 3.5, 3.0))]
+    r.add_blas_instance(r.plane_blas_index, R.trs((0, -0.5, 0), 0.0, (0, 1, 0), (120, 1, 120)), mats[1])
+    k = 0
+    for iz in range(n_side):
+        for ix in range(n_side):
+            p = ((ix - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2), rng.uniform(0.0, 0.4),
+                 (iz - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2))
+            axis = rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            sc = rng.uniform(0.6, 1.1)
+            r.add_blas_instance(blases[k % 3], R.trs(p, float(rng.uniform(0, 2 * math.pi)), tuple(axis), (sc, sc, sc)), mats[k % 6])
+            k += 1
+    return R.Camera((30, 22, 40), (0, 0, 0), (0, 1, 0), 45.0), r.total_triangle_count
+
+
 def reference_layout_bytes_per_ray(cn, spp_per_launch):
     """SURVEY.md §8(d), the figure `roofline.achieved` is defined on — REFERENCE layouts: per interior visit two
     32-B child nodes; per TLAS leaf a 144-B instance + 16-B BLAS record; per triangle test 4-B tri id + 48-B
@@ -122,6 +164,9 @@ def main():
                          "sampling, Renderer.cpp:21) instead of one frame of --spp stratified samples")
     ap.add_argument("--no-wang", action="store_true", help="N=1, --rng pcg: skip the extra measurement with the reference's RNG")
     ap.add_argument("--defocus", action="store_true", help="the C5 camera: thin lens instead of the pinhole")
+    ap.add_argument("--scene", choices=["dragon", "teapot-dragon"], default="dragon",
+                    help="dragon: the C3 workload (procedural tube, regular grid); teapot-dragon: the non-uniformly tessellated "
+                         "second stand-in (not the bench workload)")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0xFFFFFFFF,
                     help="kernel variant (default: RT_KERNEL_VARIANT_AUTO, the library's choice)")
     ap.add_argument("--shard", choices=["interleave", "frames", "rows"], default="interleave",
@@ -174,7 +219,7 @@ def main():
 
     t_setup = time.time()
     r = R.Renderer(W, H, device=local_rank)
-    cam, n_tris = build_dragon_scene(R, r, defocus=args.defocus)
+    cam, n_tris = build_dragon_scene(R, r, defocus=args.defocus) if args.scene == "dragon" else build_teapot_dragon_scene(R, r)
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1 if args.progressive else args.spp)
     r.set_option(R.OPT_MAX_DEPTH, args.depth)
     r.set_option(R.OPT_AABB_MODE, aabb_mode)
@@ -489,7 +534,7 @@ def main():
         cdoc, ckey = None, f"{label}:{'k_wf_trace' if kernel_id == 9 else 'k_render_v8'}"
         cpath = os.path.join(ROOT, "profiles", "roofline_latest.json")
         if world == 1 and os.path.exists(cpath) and \
-                (W, H, args.spp, args.depth, args.aabb, args.defocus) == (1920, 1080, 256, 8, "div", False):
+                (W, H, args.spp, args.depth, args.aabb, args.defocus, args.scene) == (1920, 1080, 256, 8, "div", False, "dragon"):
             try:
                 cdoc = json.load(open(cpath))
                 if ckey not in cdoc["kernels"]:
@@ -571,7 +616,9 @@ def main():
         "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak",  # N = 1 reports what --shard would do at N > 1 (a step is one frame whatever N)
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL: shared GPU, gloo)",
-        "config": {"workload": "C3 dragon-class stand-in (procedural, seed 1234)" + (", C5 thin-lens camera" if args.defocus else ""),
+        "config": {"workload": ("C3 dragon-class stand-in (procedural, seed 1234)" if args.scene == "dragon" else
+                                "C3b subdivided + displaced teapot.obj (non-uniform tessellation, seed 1234; NOT the bench workload)") +
+                               (", C5 thin-lens camera" if args.defocus else ""),
                    "triangles": n_tris, "image": f"{W}x{H}", "spp_per_step": args.spp, "max_depth": args.depth,
                    "sampling": f"{args.spp} progressive frames of 1 spp per step (rt_render_frames)" if args.progressive else f"one frame of {args.spp} stratified spp per step",
                    "rng": args.rng, "aabb": args.aabb, "kernel": KERNEL_NAMES.get(kernel_id, "?"), "sharding": sharding_txt},

@@ -107,6 +107,9 @@ void rth_trs(const float *position, float angle_rad, const float *axis, const fl
 /* Meshes (raytracing_amd/csrc/host/meshes.h). which: 0 plane, 1 cube, 2 sphere. */
 rth_mesh *rth_make_primitive(int which);
 rth_mesh *rth_make_dragon(uint32_t u_seg, uint32_t v_seg, uint32_t seed);
+/* a second dragon-class mesh with non-uniform tessellation: `levels` rounds of 1:4 subdivision of `base` (any mesh,
+ * e.g. a group of teapot.obj), vertices displaced along their normals by seeded noise (csrc/host/meshes.h) */
+rth_mesh *rth_make_subdivided(const rth_mesh *base, uint32_t levels, float amplitude, uint32_t seed);
 /* OBJ split by material; returns the number of groups (<0 on error, message in
  * err/err_len) and fills up to max_groups meshes, their Kd colours (3 floats
  * each) and has-material flags. */

@@ -260,6 +260,13 @@ rth_mesh *rth_make_dragon(uint32_t u_seg, uint32_t v_seg, uint32_t seed) {
   m->m = rta::make_dragon(u_seg, v_seg, seed);
   return m;
 }
+rth_mesh *rth_make_subdivided(const rth_mesh *base, uint32_t levels, float amplitude, uint32_t seed) {
+  if (!base || levels > 10)
+    return nullptr;
+  rth_mesh *m = new rth_mesh();
+  m->m = rta::subdivide_displace(base->m, levels, amplitude, seed);
+  return m;
+}
 int rth_load_obj(const char *path, rth_mesh **groups, float *group_kd, int32_t *group_has_material,
                  int max_groups, char *err, int err_len) {
   rta::ObjModel model;

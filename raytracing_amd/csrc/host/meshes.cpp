@@ -9,6 +9,7 @@
 #include <map>
 #include <sstream>
 #include <tuple>
+#include <unordered_map>
 
 #include "hmath.h"
 
@@ -183,6 +184,92 @@ Mesh make_dragon(uint32_t u_seg, uint32_t v_seg, uint32_t seed) {
         m.positions.push_back((float)P[k].z);
     m.normals.push_back((float)n.x), m.normals.push_back((float)n.y), m.normals.push_back((float)n.z);
     m.uvs.push_back((float)((double)(k / v_seg) / u_seg)), m.uvs.push_back((float)((double)(k % v_seg) / v_seg));
+  }
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// subdivided + displaced base mesh (second dragon-class stand-in)
+// ---------------------------------------------------------------------------
+namespace {
+double lattice3(int32_t i, int32_t j, int32_t k, uint32_t seed) {
+  uint32_t h = (uint32_t)i * 0x9E3779B1u ^ ((uint32_t)j * 0x85EBCA77u + seed * 0xC2B2AE3Du) ^ ((uint32_t)k * 0x27D4EB2Fu);
+  h ^= h >> 15, h *= 0x2C1B3C6Du, h ^= h >> 12, h *= 0x297A2D39u, h ^= h >> 15;
+  return (double)h / 4294967296.0;
+}
+double vnoise3(D3 p, uint32_t seed) {
+  const double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+  const int32_t ix = (int32_t)fx, iy = (int32_t)fy, iz = (int32_t)fz;
+  double a = p.x - fx, b = p.y - fy, c = p.z - fz;
+  a = a * a * (3 - 2 * a), b = b * b * (3 - 2 * b), c = c * c * (3 - 2 * c);
+  double v = 0;
+  for (int dz = 0; dz < 2; ++dz)
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx)
+        v += lattice3(ix + dx, iy + dy, iz + dz, seed) * (dx ? a : 1 - a) * (dy ? b : 1 - b) * (dz ? c : 1 - c);
+  return v;
+}
+} // namespace
+
+Mesh subdivide_displace(const Mesh &base, uint32_t levels, float amplitude, uint32_t seed) {
+  std::vector<D3> P, N;
+  std::vector<double> U, V;
+  const size_t nv0 = base.positions.size() / 3;
+  for (size_t k = 0; k < nv0; ++k) {
+    P.push_back({base.positions[3 * k], base.positions[3 * k + 1], base.positions[3 * k + 2]});
+    N.push_back({base.normals[3 * k], base.normals[3 * k + 1], base.normals[3 * k + 2]});
+    U.push_back(base.uvs.size() > 2 * k ? base.uvs[2 * k] : 0.0), V.push_back(base.uvs.size() > 2 * k + 1 ? base.uvs[2 * k + 1] : 0.0);
+  }
+  std::vector<uint32_t> idx = base.indices;
+  for (uint32_t l = 0; l < levels; ++l) {
+    std::unordered_map<uint64_t, uint32_t> mid; // edge (lo, hi) -> its midpoint vertex
+    mid.reserve(idx.size());
+    auto midpoint = [&](uint32_t a, uint32_t b) {
+      const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+      auto it = mid.find(key);
+      if (it != mid.end())
+        return it->second;
+      const uint32_t v = (uint32_t)P.size();
+      P.push_back((P[a] + P[b]) * 0.5), N.push_back(dnorm(N[a] + N[b]));
+      U.push_back((U[a] + U[b]) * 0.5), V.push_back((V[a] + V[b]) * 0.5);
+      mid.emplace(key, v);
+      return v;
+    };
+    std::vector<uint32_t> next;
+    next.reserve(idx.size() * 4);
+    for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+      const uint32_t a = idx[t], b = idx[t + 1], c = idx[t + 2];
+      const uint32_t ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+      for (uint32_t v : {a, ab, ca, ab, b, bc, ca, bc, c, ab, bc, ca})
+        next.push_back(v);
+    }
+    idx.swap(next);
+  }
+  // the base's extent sets the noise scale
+  D3 lo = P.empty() ? D3{0, 0, 0} : P[0], hi = lo;
+  for (const D3 &p : P)
+    lo = {fmin(lo.x, p.x), fmin(lo.y, p.y), fmin(lo.z, p.z)}, hi = {fmax(hi.x, p.x), fmax(hi.y, p.y), fmax(hi.z, p.z)};
+  const double extent = fmax(fmax(hi.x - lo.x, hi.y - lo.y), fmax(hi.z - lo.z, 1e-9));
+  for (size_t k = 0; k < P.size(); ++k) {
+    const D3 q = (P[k] - lo) * (1.0 / extent);
+    double d = 0, w = 1, f = 6;
+    for (uint32_t o = 0; o < 4; ++o, w *= 0.5, f *= 3.1)
+      d += w * (vnoise3(q * f, seed + o) - 0.5);
+    P[k] = P[k] + dnorm(N[k]) * (amplitude * extent * d);
+  }
+  std::vector<D3> FN(P.size(), D3{0, 0, 0});
+  for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+    const D3 fn = dcross(P[idx[t + 1]] - P[idx[t]], P[idx[t + 2]] - P[idx[t]]);
+    FN[idx[t]] = FN[idx[t]] + fn, FN[idx[t + 1]] = FN[idx[t + 1]] + fn, FN[idx[t + 2]] = FN[idx[t + 2]] + fn;
+  }
+  Mesh m;
+  m.indices = std::move(idx);
+  m.positions.reserve(P.size() * 3), m.normals.reserve(P.size() * 3), m.uvs.reserve(P.size() * 2);
+  for (size_t k = 0; k < P.size(); ++k) {
+    const D3 n = ddot(FN[k], FN[k]) > 0 ? dnorm(FN[k]) : dnorm(N[k]);
+    m.positions.push_back((float)P[k].x), m.positions.push_back((float)P[k].y), m.positions.push_back((float)P[k].z);
+    m.normals.push_back((float)n.x), m.normals.push_back((float)n.y), m.normals.push_back((float)n.z);
+    m.uvs.push_back((float)U[k]), m.uvs.push_back((float)V[k]);
   }
   return m;
 }

@@ -31,6 +31,14 @@ Mesh make_cube(float width, float height, float depth);
 // (defaults 1700 x 256 = 870,400, the size class of the Stanford dragon).
 Mesh make_dragon(uint32_t u_seg, uint32_t v_seg, uint32_t seed);
 
+// A second dragon-class mesh, with NON-UNIFORM tessellation (the tube above is a regular grid of equal triangles):
+// `levels` rounds of 1:4 midpoint subdivision of an arbitrary base mesh — its triangles keep the size ratios of the
+// base, for teapot.obj two orders of magnitude in area — with every vertex then moved along its normal by `amplitude`
+// times a four-octave value noise of its position (seeded; a function of position, so shared vertices stay shared and
+// the surface stays as closed as the base), normals recomputed area-weighted.  teapot.obj (1024 triangles) at 5 levels
+// gives 1,048,576 triangles.
+Mesh subdivide_displace(const Mesh &base, uint32_t levels, float amplitude, uint32_t seed);
+
 // One OBJ file split by material: group g holds the faces that `usemtl` g.
 struct ObjMaterial {
   std::string name;

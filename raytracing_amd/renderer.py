@@ -32,7 +32,7 @@ HOST_SYMBOLS = [
     "rth_add_blas_instance", "rth_set_blas_instance_transform", "rth_remove_blas",
     "rth_remove_blas_instance", "rth_primitive_blas", "rth_total_triangle_count", "rth_scene_desc",
     "rth_camera_uniforms", "rth_read_image", "rth_wait", "rth_context", "rth_last_error", "rth_trs",
-    "rth_make_primitive", "rth_make_dragon", "rth_load_obj", "rth_load_scene_file", "rth_mesh_free", "rth_mesh_vertex_count",
+    "rth_make_primitive", "rth_make_dragon", "rth_make_subdivided", "rth_load_obj", "rth_load_scene_file", "rth_mesh_free", "rth_mesh_vertex_count",
     "rth_mesh_index_count", "rth_mesh_positions", "rth_mesh_normals", "rth_mesh_uvs",
     "rth_mesh_indices", "rth_build_blas", "rth_refit_blas", "rth_build_tlas", "rth_tlas_leaves", "rth_tlas_cluster",
     "rth_last_tlas_build", "rth_mat4_inverse",
@@ -100,6 +100,7 @@ def lib():
     L.rth_trs.argtypes = [vp, f32, vp, vp, vp]; L.rth_trs.restype = None
     L.rth_make_primitive.argtypes = [C.c_int]; L.rth_make_primitive.restype = vp
     L.rth_make_dragon.argtypes = [u32, u32, u32]; L.rth_make_dragon.restype = vp
+    L.rth_make_subdivided.argtypes = [vp, u32, f32, u32]; L.rth_make_subdivided.restype = vp
     L.rth_load_obj.argtypes = [C.c_char_p, C.POINTER(vp), vp, vp, C.c_int, C.c_char_p, C.c_int]
     L.rth_load_scene_file.argtypes = [vp, C.c_char_p, C.POINTER(SceneInfoC), C.c_char_p, C.c_int]
     L.rth_load_scene_file.restype = C.c_int64
@@ -162,6 +163,13 @@ class Mesh:
     @classmethod
     def dragon(cls, u_seg=1700, v_seg=256, seed=1234):
         return cls(lib().rth_make_dragon(u_seg, v_seg, seed))
+
+    def subdivided(self, levels, amplitude=0.02, seed=1234):
+        """`levels` rounds of 1:4 subdivision of this mesh + seeded displacement along the normals (meshes.h)."""
+        h = lib().rth_make_subdivided(self._h, levels, amplitude, seed)
+        if not h:
+            raise RendererError("rth_make_subdivided failed")
+        return Mesh(h)
 
     @staticmethod
     def load_obj(path, max_groups=64):

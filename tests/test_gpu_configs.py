@@ -343,3 +343,41 @@ def test_kernel9_without_memory_falls_back_to_kernel8_in_automatic_mode():
     c = _launch(r, cam, 9)
     assert _last_kernel(r) == 9 and _same(c, want)
     r.shutdown()
+
+
+def test_c3b_nonuniformly_tessellated_mesh_full_size():
+    """A second dragon-class mesh whose triangles are NOT all of one size (teapot.obj subdivided to 1,048,576 triangles
+    and displaced, bench.build_teapot_dragon_scene; the C3 tube is a regular grid): the same checks as C3 — kernel 0 ==
+    default kernel, shares stitch, 40 oracle rows (Wang, 4 spp) — and the wavefront pipeline against the megakernel at
+    64 spp and against the oracle at 4 spp (keyed PCG).  The BVH is deeper (leaf depth up to 41, tools/leaf_histogram.py)."""
+    import bench
+    w, h, depth = 1920, 1080, 8
+    r = R.Renderer(w, h, device=0)
+    cam, n_tris = bench.build_teapot_dragon_scene(R, r)
+    assert n_tris == 1048578
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 4)
+    _properties_and_oracle_rows(r, cam, w, h, 2, depth, T.RNG_WANG)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 64)
+    a = _launch(r, cam, 9)
+    assert _last_kernel(r) == 9 and _same(a, _launch(r, cam, 8))
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 4)
+    b = _launch(r, cam, 9)
+    rows, want = _oracle_rows(r, cam, w, h, 2, depth, T.RNG_PCG, 33)
+    assert _same(b[rows], want[rows])
+    r.shutdown()
+
+
+def test_c4_many_instances_at_full_size():
+    """C4 at 1920x1080 and 64 spp (the reduced-size whole-image check is test_gpu_parity.py::test_many_instances_c4_scale):
+    2025 transformed instances, four material types — the property checks and 40 oracle rows of the other full-size
+    configs."""
+    import bench
+    w, h, depth = 1920, 1080, 8
+    r = R.Renderer(w, h, device=0)
+    cam, _ = bench.build_instances_scene(R, r)
+    r.set_option(R.OPT_MAX_DEPTH, depth)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 64)
+    _properties_and_oracle_rows(r, cam, w, h, 8, depth, T.RNG_WANG)
+    r.shutdown()

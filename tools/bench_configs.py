@@ -46,22 +46,7 @@ rows.append((f"C2 teapot.obj, {SPP} spp, depth 8",) + measure(r, cam, SPP, 8))
 r.shutdown()
 # C4: 45 x 45 instances of teapot / sphere / cube, mixed materials (the parity test's scene class)
 r = R.Renderer(W, H, device=0)
-rng = np.random.default_rng(7)
-(tea, _, _), = R.Mesh.load_obj(os.path.join(S.ASSETS, "teapot.obj"))
-blases = [r.cube_blas_index, r.sphere_blas_index, r.add_blas(tea)]
-mats = [r.default_material, r.add_lambert_material((0.8, 0.3, 0.2)), r.add_metal_material((0.8, 0.8, 0.9), 0.05),
-        r.add_metal_material((0.9, 0.6, 0.2), 0.4), r.add_dielectric_material(1.5), r.add_emissive_material((4.0, 3.5, 3.0))]
-r.add_blas_instance(r.plane_blas_index, R.trs((0, -0.5, 0), 0.0, (0, 1, 0), (120, 1, 120)), mats[1])
-n_side, k = 45, 0
-for iz in range(n_side):
-    for ix in range(n_side):
-        p = ((ix - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2), rng.uniform(0.0, 0.4),
-             (iz - (n_side - 1) / 2) * 1.6 + rng.uniform(-0.2, 0.2))
-        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
-        s = rng.uniform(0.6, 1.1)
-        r.add_blas_instance(blases[k % 3], R.trs(p, float(rng.uniform(0, 2 * math.pi)), tuple(axis), (s, s, s)), mats[k % 6])
-        k += 1
-cam = R.Camera((30, 22, 40), (0, 0, 0), (0, 1, 0), 45.0)
+cam, _ = bench.build_instances_scene(R, r)
 rows.append((f"C4 2025 instances (teapot/sphere/cube, 4 material types), {SPP} spp, depth 8",) + measure(r, cam, SPP, 8))
 r.shutdown()
 # C5 camera on the C3 scene: defocus blur, 3840 wide
@@ -69,6 +54,16 @@ r = R.Renderer(3840, 2160, device=0)
 cam, _ = bench.build_dragon_scene(R, r)
 cam.c.defocus_angle, cam.c.focus_dist = 0.8, 4.2
 rows.append((f"C5 dragon stand-in 3840x2160 with defocus blur, {SPP} spp, depth 8 (one GPU)",) + measure(r, cam, SPP, 8, frames=2))
+r.shutdown()
+# C3b: the non-uniformly tessellated second dragon-class mesh (bench.build_teapot_dragon_scene)
+r = R.Renderer(W, H, device=0)
+cam, _ = bench.build_teapot_dragon_scene(R, r)
+rows.append((f"C3b subdivided + displaced teapot (1,048,576 triangles, non-uniform), {SPP} spp, depth 8",) + measure(r, cam, SPP, 8))
+r.shutdown()
+# C3 itself, for the same settings (bench.py is the authoritative number)
+r = R.Renderer(W, H, device=0)
+cam, _ = bench.build_dragon_scene(R, r)
+rows.append((f"C3 dragon stand-in (regular tube), {SPP} spp, depth 8",) + measure(r, cam, SPP, 8))
 r.shutdown()
 for name, ms, mrays, tris, kern in rows:
     print(f"[{RNG}] {name}: {tris} triangles (incl. primitives), kernel {kern}, {ms:.1f} ms per launch, {mrays:.0f} Mrays/s")
