@@ -128,25 +128,31 @@ inline uint8_t clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : (uint8_t)x)
 // a column pass that keeps 2 extra bits (rounding +512 then >> 10; a column whose AC terms are all zero is d0 * 4),
 // a row pass that removes 17 bits with rounding 65536 and adds the level shift 128 before the shift.
 inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
+// (unsigned arithmetic: a crafted file can drive the intermediate sums past 31 bits, which must wrap like stb_image's
+//  two's-complement ints do in practice instead of being undefined behaviour; for every valid file the values are the same)
 struct Idct1D {
   int x0, x1, x2, x3, t0, t1, t2, t3;
-  Idct1D(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-    static const int c0 = f2f(0.5411961f), c1 = f2f(-1.847759065f), c2 = f2f(0.765366865f), c3 = f2f(1.175875602f),
-                     c4 = f2f(0.298631336f), c5 = f2f(2.053119869f), c6 = f2f(3.072711026f), c7 = f2f(1.501321110f),
-                     c8 = f2f(-0.899976223f), c9 = f2f(-2.562915447f), c10 = f2f(-1.961570560f), c11 = f2f(-0.390180644f);
-    int p1 = (s2 + s6) * c0;
-    const int e2 = p1 + s6 * c1, e3 = p1 + s2 * c2;
-    const int e0 = (s0 + s4) * 4096, e1 = (s0 - s4) * 4096;
-    x0 = e0 + e3, x3 = e0 - e3, x1 = e1 + e2, x2 = e1 - e2;
-    int o0 = s7, o1 = s5, o2 = s3, o3 = s1;
-    int p3 = o0 + o2, p4 = o1 + o3, p2 = o1 + o2;
+  Idct1D(int s0_, int s1_, int s2_, int s3_, int s4_, int s5_, int s6_, int s7_) {
+    typedef uint32_t U;
+    static const U c0 = (U)f2f(0.5411961f), c1 = (U)f2f(-1.847759065f), c2 = (U)f2f(0.765366865f), c3 = (U)f2f(1.175875602f),
+                   c4 = (U)f2f(0.298631336f), c5 = (U)f2f(2.053119869f), c6 = (U)f2f(3.072711026f), c7 = (U)f2f(1.501321110f),
+                   c8 = (U)f2f(-0.899976223f), c9 = (U)f2f(-2.562915447f), c10 = (U)f2f(-1.961570560f), c11 = (U)f2f(-0.390180644f);
+    const U s0 = (U)s0_, s1 = (U)s1_, s2 = (U)s2_, s3 = (U)s3_, s4 = (U)s4_, s5 = (U)s5_, s6 = (U)s6_, s7 = (U)s7_;
+    U p1 = (s2 + s6) * c0;
+    const U e2 = p1 + s6 * c1, e3 = p1 + s2 * c2;
+    const U e0 = (s0 + s4) * 4096u, e1 = (s0 - s4) * 4096u;
+    x0 = (int)(e0 + e3), x3 = (int)(e0 - e3), x1 = (int)(e1 + e2), x2 = (int)(e1 - e2);
+    U o0 = s7, o1 = s5, o2 = s3, o3 = s1;
+    U p3 = o0 + o2, p4 = o1 + o3, p2 = o1 + o2;
     p1 = o0 + o3;
-    const int p5 = (p3 + p4) * c3;
+    const U p5 = (p3 + p4) * c3;
     o0 *= c4, o1 *= c5, o2 *= c6, o3 *= c7;
     p1 = p5 + p1 * c8, p2 = p5 + p2 * c9, p3 *= c10, p4 *= c11;
-    t3 = o3 + p1 + p4, t2 = o2 + p2 + p3, t1 = o1 + p2 + p4, t0 = o0 + p1 + p3;
+    t3 = (int)(o3 + p1 + p4), t2 = (int)(o2 + p2 + p3), t1 = (int)(o1 + p2 + p4), t0 = (int)(o0 + p1 + p3);
   }
 };
+inline int wadd(int a, int b) { return (int)((uint32_t)a + (uint32_t)b); }
+inline int wsub(int a, int b) { return (int)((uint32_t)a - (uint32_t)b); }
 
 void idct_block(uint8_t *out, size_t stride, const short d[64]) {
   int val[64];
@@ -154,16 +160,16 @@ void idct_block(uint8_t *out, size_t stride, const short d[64]) {
     const short *c = d + i;
     int *v = val + i;
     if (!c[8] && !c[16] && !c[24] && !c[32] && !c[40] && !c[48] && !c[56]) {
-      const int dc = c[0] * 4;
+      const int dc = (int)((uint32_t)(int)c[0] * 4u);
       for (int k = 0; k < 8; ++k)
         v[8 * k] = dc;
     } else {
       Idct1D r(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
-      const int x0 = r.x0 + 512, x1 = r.x1 + 512, x2 = r.x2 + 512, x3 = r.x3 + 512;
-      v[0] = (x0 + r.t3) >> 10, v[56] = (x0 - r.t3) >> 10;
-      v[8] = (x1 + r.t2) >> 10, v[48] = (x1 - r.t2) >> 10;
-      v[16] = (x2 + r.t1) >> 10, v[40] = (x2 - r.t1) >> 10;
-      v[24] = (x3 + r.t0) >> 10, v[32] = (x3 - r.t0) >> 10;
+      const int x0 = wadd(r.x0, 512), x1 = wadd(r.x1, 512), x2 = wadd(r.x2, 512), x3 = wadd(r.x3, 512);
+      v[0] = wadd(x0, r.t3) >> 10, v[56] = wsub(x0, r.t3) >> 10;
+      v[8] = wadd(x1, r.t2) >> 10, v[48] = wsub(x1, r.t2) >> 10;
+      v[16] = wadd(x2, r.t1) >> 10, v[40] = wsub(x2, r.t1) >> 10;
+      v[24] = wadd(x3, r.t0) >> 10, v[32] = wsub(x3, r.t0) >> 10;
     }
   }
   for (int i = 0; i < 8; ++i) {
@@ -171,11 +177,11 @@ void idct_block(uint8_t *out, size_t stride, const short d[64]) {
     uint8_t *o = out + stride * i;
     Idct1D r(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     const int bias = 65536 + (128 << 17);
-    const int x0 = r.x0 + bias, x1 = r.x1 + bias, x2 = r.x2 + bias, x3 = r.x3 + bias;
-    o[0] = clamp255((x0 + r.t3) >> 17), o[7] = clamp255((x0 - r.t3) >> 17);
-    o[1] = clamp255((x1 + r.t2) >> 17), o[6] = clamp255((x1 - r.t2) >> 17);
-    o[2] = clamp255((x2 + r.t1) >> 17), o[5] = clamp255((x2 - r.t1) >> 17);
-    o[3] = clamp255((x3 + r.t0) >> 17), o[4] = clamp255((x3 - r.t0) >> 17);
+    const int x0 = wadd(r.x0, bias), x1 = wadd(r.x1, bias), x2 = wadd(r.x2, bias), x3 = wadd(r.x3, bias);
+    o[0] = clamp255(wadd(x0, r.t3) >> 17), o[7] = clamp255(wsub(x0, r.t3) >> 17);
+    o[1] = clamp255(wadd(x1, r.t2) >> 17), o[6] = clamp255(wsub(x1, r.t2) >> 17);
+    o[2] = clamp255(wadd(x2, r.t1) >> 17), o[5] = clamp255(wsub(x2, r.t1) >> 17);
+    o[3] = clamp255(wadd(x3, r.t0) >> 17), o[4] = clamp255(wsub(x3, r.t0) >> 17);
   }
 }
 
@@ -307,8 +313,8 @@ struct Decoder {
       return fail("bad component count");
     if (end - p < 6 + 3 * (size_t)ncomp)
       return fail("frame header cut short");
-    if ((uint64_t)width * height > (1ull << 28))
-      return fail("image too large");
+    if ((uint64_t)width * height > (1ull << 26)) // 8192 x 8192: the planes, coefficients and RGBA of a larger one run to gigabytes
+      return fail("image too large (more than 2^26 pixels)");
     static const char rgb[3] = {'R', 'G', 'B'};
     rgb_ids = ncomp == 3;
     for (int i = 0; i < ncomp; ++i) {
@@ -349,8 +355,13 @@ struct Decoder {
     if (t < 0 || t > 15)
       return fail("bad Huffman code");
     const int diff = t ? extend(br.receive(t), t) : 0;
+    if (diff > 65535 || diff < -65535 || c.dc_pred + diff > 32767 || c.dc_pred + diff < -32768)
+      return fail("bad DC delta"); // (stb_image refuses these too: the prediction must stay a 16-bit value)
     c.dc_pred += diff;
-    data[0] = (short)(c.dc_pred * q[0]);
+    const long long dcq = (long long)c.dc_pred * q[0];
+    if (dcq > 32767 || dcq < -32768)
+      return fail("DC coefficient out of range");
+    data[0] = (short)dcq;
     for (int k = 1; k < 64;) {
       const int rs = decode_symbol(br, ac[c.ta]);
       if (rs < 0)
@@ -380,8 +391,14 @@ struct Decoder {
       const int t = decode_symbol(br, dc[c.td]);
       if (t < 0 || t > 15)
         return fail("bad Huffman code");
-      c.dc_pred += t ? extend(br.receive(t), t) : 0;
-      d[0] = (short)(c.dc_pred * (1 << al));
+      const int diff = t ? extend(br.receive(t), t) : 0;
+      if (c.dc_pred + diff > 32767 || c.dc_pred + diff < -32768)
+        return fail("bad DC delta");
+      c.dc_pred += diff;
+      const long long dcs = (long long)c.dc_pred * (1 << al);
+      if (dcs > 32767 || dcs < -32768)
+        return fail("DC coefficient out of range");
+      d[0] = (short)dcs;
     } else if (br.bit()) {
       d[0] = (short)(d[0] + (1 << al));
     }
@@ -519,6 +536,8 @@ struct Decoder {
         while (br.p < br.end && !(br.p[0] == 0xFF && br.p + 1 < br.end && br.p[1] != 0x00))
           ++br.p;
       }
+      while (br.p + 2 < br.end && br.p[0] == 0xFF && br.p[1] == 0xFF) // fill bytes before a marker (T.81 B.1.1.2)
+        ++br.p;
       if (br.p + 1 >= br.end || br.p[0] != 0xFF || br.p[1] != (0xD0 + next_rst))
         return true; // no restart marker here: the scan ends (what follows is left to the marker loop)
       br.p += 2;

@@ -53,6 +53,23 @@ try:
         for t in range(1, 6):
             (out / f"cut_{k}_{t}.jpg").write_bytes(raw[: len(raw) * t // 6])
         flips(raw, f"flip_{k}_{{}}.jpg", 24, 0, 256, first=2, per=2)
+        # crafted: quantisers at their maximum so that DC * q and the IDCT sums leave 16 / 31 bits; scan data
+        # replaced by long runs of one-bits and of random bytes (unbounded DC deltas); 0xFF fill bytes before RSTn
+        b = bytearray(raw)
+        pos = 2
+        while pos + 4 <= len(b) and b[pos] == 0xFF and b[pos + 1] != 0xDA:
+            ln = (b[pos + 2] << 8) | b[pos + 3]
+            if b[pos + 1] == 0xDB:
+                for q in range(pos + 5, pos + 2 + ln):
+                    b[q] = 0xFF
+            pos += 2 + ln
+        (out / f"maxq_{k}.jpg").write_bytes(bytes(b))
+        sos = raw.find(b"\xff\xda")
+        if sos > 0:
+            hdr = sos + 2 + ((raw[sos + 2] << 8) | raw[sos + 3])
+            for t, fill in enumerate((b"\xfe" * 4000, bytes(rng.integers(0, 255, 4000, dtype=np.uint8).tolist()), b"\x7f\xfe" * 2000)):
+                (out / f"scan_{k}_{t}.jpg").write_bytes(bytes(b[:hdr]) + fill + b"\xff\xd9")
+            (out / f"fill_{k}.jpg").write_bytes(raw.replace(b"\xff\xd0", b"\xff\xff\xff\xd0").replace(b"\xff\xd1", b"\xff\xff\xd1"))
 except ImportError:
     pass
 
