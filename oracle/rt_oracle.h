@@ -5,12 +5,17 @@
  * product (raytracing_amd/, librt_hip.so, librt_host.so) never links, loads or
  * calls anything declared here.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- * for this path and its own implementation (Slang GPU code
- * + Windows/Vulkan/glm host code) cannot be built or run here.  The oracle is a
+ * PARITY: the reference ships no tests, golden vectors or fixtures for this
+ * path and its own implementation (Slang GPU code +
+ * Windows/Vulkan/glm host code) cannot be built or run here.  The oracle is a
  * line-by-line CPU restatement of the reference sources cited at each function
- * in rt_oracle.cpp, pinned only by known-answer tests derived by hand from
- * those sources (tests/test_oracle_*.py).
+ * in rt_oracle.cpp.  PINNED against the one output the reference holds — its
+ * Screenshot3.png render of Scenes/TestScene.json (tests/golden/screenshot3.npz,
+ * tests/test_reference_screenshot.py): scene loading, camera and pixel mapping
+ * (silhouettes to the pixel) and Lambert / sky transport in absolute 8-bit
+ * levels.  UNPINNED (restatement + hand-derived known answers only,
+ * tests/test_oracle_kat.py, tests/test_appendix_c.py): hit ids, RNG sequence,
+ * traversal order, metal / dielectric / emissive, instancing.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

@@ -403,7 +403,7 @@ def test_dielectric_condition_both_readings(ctx, variant, rng):
             _same_image(got, O.render(sc, cam, p, nthreads=8))
             imgs.append(got)
         with pytest.raises(_ffi.RtError):
-            ctx.render(O.render_params(w, h, 0, 1, 3, flags=2))  # unknown flag bit
+            ctx.render(O.render_params(w, h, 0, 1, 3, flags=4))  # unknown flag bit
     finally:
         ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
     differ = not np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
@@ -534,8 +534,20 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
         c.render(p2)
         O.render(sc, cam, p2, want, nthreads=8)
         _same_image(c.read_accum(w, h), want)
-        with pytest.raises(_ffi.RtError, match="PCG"):
-            c.render(O.render_params(w, h, 3, 1, 3, rng_mode=T.RNG_WANG))
+        # the reference's sequential RNG on kernel 9 (round 3): a frame's samples run one after the other inside a slot
+        # (only frame batches give it parallelism, tests/test_gpu_frames.py); a single frame is simply correct
+        acc = c.read_accum(w, h)
+        pw = O.render_params(w, h, 7, 2, 5, rng_mode=T.RNG_WANG)
+        pw.accum_count = 3
+        c.render(pw)
+        O.render(sc, cam, pw, want, nthreads=8)
+        _same_image(c.read_accum(w, h), want)
+        c.clear_accum()  # back to where the checks below expect the image: frames 0 .. 2
+        want[:] = 0
+        for q in (O.render_params(w, h, 0, 3, 6, rng_mode=T.RNG_PCG), p1, p2):
+            c.render(q)
+            O.render(sc, cam, q, want, nthreads=8)
+        assert np.array_equal(c.read_accum(w, h).view(np.uint32), acc.view(np.uint32))
         with pytest.raises(_ffi.RtError, match="2\\^28"):  # the depth word's top bits are kernel 9's flags
             c.render(O.render_params(w, h, 3, 1, 1 << 28, rng_mode=T.RNG_PCG))
         c.render(O.render_params(w, h, 3, 1, (1 << 28) - 1, rng_mode=T.RNG_PCG))  # the largest depth it takes
