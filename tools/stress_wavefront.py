@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress of kernel 9's round scheduling on the GPU alone: generated scenes (tests/test_gpu_random_scenes.py) at sizes
 the oracle would take minutes for, kernel 9 with random budgets and scheduling settings against kernel 0 (one lane
-per pixel, no scheduling at all) — images must be equal bit for bit, ray counts equal.  Usage: stress_wavefront.py [cases]"""
+per pixel, no scheduling at all) — images must be equal bit for bit, ray counts equal.  Round 3: either RNG and batches
+of 1 ... 9 progressive frames (rt_render_frames).  Usage: stress_wavefront.py [cases]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -23,10 +24,13 @@ for seed in range(500, 500 + cases):
         c.resize(w, h)
         sqrt_spp, depth = int(rng.integers(2, 7)), int(rng.choice([2, 3, 5, 8, 17]))
         aabb = int(rng.choice([T.AABB_DIV, T.AABB_DIV, T.AABB_RCP]))
-        p = O.render_params(w, h, 0, sqrt_spp, depth, rng_mode=T.RNG_PCG, aabb_mode=aabb)
+        rng_mode, nf = int(rng.choice([T.RNG_PCG, T.RNG_WANG])), int(rng.choice([1, 1, 2, 5, 9]))
+        if nf > 1:
+            sqrt_spp = min(sqrt_spp, 3)
+        p = O.render_params(w, h, int(rng.integers(0, 50)), sqrt_spp, depth, rng_mode=rng_mode, aabb_mode=aabb)
         c.set_kernel_variant(0)
         c.reset_stats()
-        c.render(p)
+        c.render_frames(p, nf)
         want, rays0 = c.read_accum(w, h).copy(), c.stats().rays_traced
         paths = w * h * sqrt_spp * sqrt_spp
         for rep in range(3):
@@ -40,13 +44,13 @@ for seed in range(500, 500 + cases):
             c.wavefront_tuning(*tuning)
             c.clear_accum()
             c.reset_stats()
-            c.render(p)
+            c.render_frames(p, nf)
             got, rays9 = c.read_accum(w, h), c.stats().rays_traced
             diff = int((got.view(np.uint32) != want.view(np.uint32)).any(-1).sum())
             counts = c.wavefront_counts()
             ok = diff == 0 and rays9 == rays0
             bad += 0 if ok else 1
-            print(f"seed {seed} {w}x{h} spp {sqrt_spp**2} depth {depth} paths {paths} budget {budget} tuning {tuning}: "
+            print(f"seed {seed} {w}x{h} rng {rng_mode} frames {nf} spp {sqrt_spp**2} depth {depth} paths {paths} budget {budget} tuning {tuning}: "
                   f"rounds/list/suspended/finished {counts} differing {diff} rays {rays9} vs {rays0} {'ok' if ok else 'MISMATCH'}", flush=True)
     finally:
         c.close()
