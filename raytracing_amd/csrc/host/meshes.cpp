@@ -24,75 +24,77 @@ const float kPiF = 3.14159265358979323846264338327950288f;   // glm::pi<float>()
 const float kTwoPiF = 6.28318530717958647692528676655900576f; // glm::two_pi<float>()
 } // namespace
 
-// src/Renderer.cpp:64-107
-Mesh make_sphere(float radius, uint32_t segments, uint32_t rings) {
+// The reference's three procedural primitives (generate_sphere / generate_plane / generate_cube,
+// src/Renderer.cpp:64-213) produce BLAS 0 / 1 / 2 of every scene, so vertex values, vertex order and triangle
+// order must be theirs to the bit (the BVH and every hit id follow from them).  Sphere and plane are both a
+// (cols + 1) x (rows + 1) lattice over [0, 1]^2 whose cells split into the triangles (a, below, a + 1) and
+// (a + 1, below, below + 1); one lattice builder serves both, the surface comes in as a function of the lattice
+// coordinates.  The cube is six quads from a corner-sign table.
+namespace {
+template <typename Surface> Mesh lattice_mesh(uint32_t cols, uint32_t rows, Surface surface) {
   Mesh m;
-  for (uint32_t y = 0; y <= rings; ++y) {
-    float v = float(y) / rings;
-    float theta = v * kPiF;
-    for (uint32_t x = 0; x <= segments; ++x) {
-      float u = float(x) / segments;
-      float phi = u * kTwoPiF;
-      float sin_theta = sinf(theta), cos_theta = cosf(theta);
-      float sin_phi = sinf(phi), cos_phi = cosf(phi);
-      vec3 normal(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
-      push3(m.positions, vec3(0.f) + radius * normal);
+  const uint32_t pitch = cols + 1;
+  m.positions.reserve((size_t)pitch * (rows + 1) * 3);
+  for (uint32_t r = 0; r <= rows; ++r) {
+    const float t = float(r) / rows; // second lattice coordinate (v of the sphere, vz of the plane)
+    for (uint32_t c = 0; c <= cols; ++c) {
+      const float s = float(c) / cols;
+      vec3 position, normal;
+      surface(s, t, position, normal);
+      push3(m.positions, vec3(0.f) + position); // (`center + ...` with the reference's default centre: -0 becomes +0)
       push3(m.normals, normal);
-      push2(m.uvs, u, v);
+      push2(m.uvs, s, t);
     }
   }
-  for (uint32_t y = 0; y < rings; ++y)
-    for (uint32_t x = 0; x < segments; ++x) {
-      uint32_t i0 = y * (segments + 1) + x, i1 = i0 + segments + 1;
-      for (uint32_t i : {i0, i1, i0 + 1, i0 + 1, i1, i1 + 1})
-        m.indices.push_back(i);
+  m.indices.reserve((size_t)cols * rows * 6);
+  for (uint32_t r = 0; r < rows; ++r)
+    for (uint32_t c = 0; c < cols; ++c) {
+      const uint32_t a = r * pitch + c, below = a + pitch;
+      const uint32_t cell[6] = {a, below, a + 1, a + 1, below, below + 1};
+      m.indices.insert(m.indices.end(), cell, cell + 6);
     }
   return m;
 }
+} // namespace
 
-// src/Renderer.cpp:109-145
-Mesh make_plane(float width, float depth, uint32_t x_segments, uint32_t z_segments) {
-  Mesh m;
-  for (uint32_t z = 0; z <= z_segments; ++z) {
-    float vz = float(z) / z_segments;
-    float pos_z = (vz - 0.5f) * depth;
-    for (uint32_t x = 0; x <= x_segments; ++x) {
-      float ux = float(x) / x_segments;
-      float pos_x = (ux - 0.5f) * width;
-      push3(m.positions, vec3(0.f) + vec3(pos_x, 0.f, pos_z));
-      push3(m.normals, vec3(0.f, 1.f, 0.f));
-      push2(m.uvs, ux, vz);
-    }
-  }
-  for (uint32_t z = 0; z < z_segments; ++z)
-    for (uint32_t x = 0; x < x_segments; ++x) {
-      uint32_t i0 = z * (x_segments + 1) + x, i1 = i0 + x_segments + 1;
-      for (uint32_t i : {i0, i1, i0 + 1, i0 + 1, i1, i1 + 1})
-        m.indices.push_back(i);
-    }
-  return m;
+Mesh make_sphere(float radius, uint32_t segments, uint32_t rings) { // Renderer.cpp:64-107
+  return lattice_mesh(segments, rings, [radius](float u, float v, vec3 &position, vec3 &normal) {
+    const float polar = v * kPiF, azimuth = u * kTwoPiF;
+    const float sp = sinf(polar), cp = cosf(polar), sa = sinf(azimuth), ca = cosf(azimuth);
+    normal = vec3(sp * ca, cp, sp * sa);
+    position = radius * normal;
+  });
 }
 
-// src/Renderer.cpp:147-213
-Mesh make_cube(float width, float height, float depth) {
+Mesh make_plane(float width, float depth, uint32_t x_segments, uint32_t z_segments) { // Renderer.cpp:109-145
+  return lattice_mesh(x_segments, z_segments, [width, depth](float ux, float vz, vec3 &position, vec3 &normal) {
+    position = vec3((ux - 0.5f) * width, 0.f, (vz - 0.5f) * depth);
+    normal = vec3(0.f, 1.f, 0.f);
+  });
+}
+
+Mesh make_cube(float width, float height, float depth) { // Renderer.cpp:147-213
+  // faces in the reference's order (+Z, -Z, -X, +X, +Y, -Y); per face its four corners as signs of the half extents,
+  // counter-clockwise seen from outside, with uv (0,0) (1,0) (1,1) (0,1) and the triangles (0,1,2) (0,2,3)
+  static const int8_t kFace[6][4][3] = {
+      {{-1, -1, +1}, {+1, -1, +1}, {+1, +1, +1}, {-1, +1, +1}}, {{+1, -1, -1}, {-1, -1, -1}, {-1, +1, -1}, {+1, +1, -1}},
+      {{-1, -1, -1}, {-1, -1, +1}, {-1, +1, +1}, {-1, +1, -1}}, {{+1, -1, +1}, {+1, -1, -1}, {+1, +1, -1}, {+1, +1, +1}},
+      {{-1, +1, +1}, {+1, +1, +1}, {+1, +1, -1}, {-1, +1, -1}}, {{-1, -1, -1}, {+1, -1, -1}, {+1, -1, +1}, {-1, -1, +1}}};
+  static const int8_t kNormal[6][3] = {{0, 0, 1}, {0, 0, -1}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+  static const float kUv[4][2] = {{0.f, 0.f}, {1.f, 0.f}, {1.f, 1.f}, {0.f, 1.f}};
+  const float half[3] = {width * 0.5f, height * 0.5f, depth * 0.5f};
   Mesh m;
-  float hx = width * 0.5f, hy = height * 0.5f, hz = depth * 0.5f;
-  auto face = [&](vec3 v0, vec3 v1, vec3 v2, vec3 v3, vec3 n) {
-    uint32_t base = (uint32_t)(m.positions.size() / 3);
-    for (vec3 v : {v0, v1, v2, v3}) {
-      push3(m.positions, vec3(0.f) + v);
-      push3(m.normals, n);
+  for (int f = 0; f < 6; ++f) {
+    const uint32_t first = (uint32_t)(m.positions.size() / 3);
+    for (int k = 0; k < 4; ++k) {
+      const int8_t *sg = kFace[f][k];
+      push3(m.positions, vec3(0.f) + vec3(sg[0] < 0 ? -half[0] : half[0], sg[1] < 0 ? -half[1] : half[1], sg[2] < 0 ? -half[2] : half[2]));
+      push3(m.normals, vec3((float)kNormal[f][0], (float)kNormal[f][1], (float)kNormal[f][2]));
+      push2(m.uvs, kUv[k][0], kUv[k][1]);
     }
-    push2(m.uvs, 0, 0), push2(m.uvs, 1, 0), push2(m.uvs, 1, 1), push2(m.uvs, 0, 1);
-    for (uint32_t i : {0u, 1u, 2u, 0u, 2u, 3u})
-      m.indices.push_back(base + i);
-  };
-  face({-hx, -hy, hz}, {hx, -hy, hz}, {hx, hy, hz}, {-hx, hy, hz}, {0, 0, 1});
-  face({hx, -hy, -hz}, {-hx, -hy, -hz}, {-hx, hy, -hz}, {hx, hy, -hz}, {0, 0, -1});
-  face({-hx, -hy, -hz}, {-hx, -hy, hz}, {-hx, hy, hz}, {-hx, hy, -hz}, {-1, 0, 0});
-  face({hx, -hy, hz}, {hx, -hy, -hz}, {hx, hy, -hz}, {hx, hy, hz}, {1, 0, 0});
-  face({-hx, hy, hz}, {hx, hy, hz}, {hx, hy, -hz}, {-hx, hy, -hz}, {0, 1, 0});
-  face({-hx, -hy, -hz}, {hx, -hy, -hz}, {hx, -hy, hz}, {-hx, -hy, hz}, {0, -1, 0});
+    for (uint32_t k : {0u, 1u, 2u, 0u, 2u, 3u})
+      m.indices.push_back(first + k);
+  }
   return m;
 }
 
