@@ -290,9 +290,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # With no kernel named, the library times kernel 9 and kernel 8 once each on a new keyed-PCG launch shape and keeps
-    # the faster (rt_hip.h, rt_set_kernel_variant): two launches of set-up, like the BVH build, before the warmup
-    settle = 2 if ((args.rng == "pcg" or args.progressive) and args.variant == _ffi.KERNEL_VARIANT_AUTO) else 0
+    # With no kernel named, the library warms kernel 9 up, then times kernel 9 and kernel 8 once each on a new launch
+    # shape and keeps the faster (rt_hip.h, rt_set_kernel_variant): three launches of set-up, like the BVH build, before the warmup
+    settle = 3 if ((args.rng == "pcg" or args.progressive) and args.variant == _ffi.KERNEL_VARIANT_AUTO) else 0
     for _ in range(settle):
         step()
     fence()
@@ -352,7 +352,7 @@ def main():
         r.set_option(R.OPT_RNG_MODE, T.RNG_WANG)
         single = timed(step, 0)
         r.set_option(R.OPT_SAMPLES_PER_PIXEL, 1)
-        wang = timed(lambda: r.render_frames(cam, args.spp), 2 if args.variant == _ffi.KERNEL_VARIANT_AUTO else 0)
+        wang = timed(lambda: r.render_frames(cam, args.spp), 3 if args.variant == _ffi.KERNEL_VARIANT_AUTO else 0)
         wang["note"] = (f"same scene, size and depth with rng_mode = RT_RNG_WANG (Random.slang:7-19): a step = {args.spp} progressive "
                         "frames of 1 sample per pixel (the reference's own sampling, Renderer.cpp:21) in one rt_render_frames call")
         single["note"] = f"one frame of {args.spp} stratified samples per pixel, Wang RNG: one launch of the megakernel"

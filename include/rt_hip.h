@@ -118,8 +118,10 @@ int rt_reset_stats(rt_ctx *ctx);
  * depth 3 per launch (the reference's live configuration), and except launches of at least 2e7 independent units of
  * work — pixels x frames x samples under RT_RNG_PCG (1920x1080 from 10 samples per pixel on), pixels x frames under
  * RT_RNG_WANG (rt_render_frames from 10 frames on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
- * launch of a (scene, launch shape) runs kernel 9, the second kernel 8, both timed (rt_render waits for them), and
- * the following ones the faster of the two.  The choice belongs to the uploaded scene and the launch shape:
+ * launches of a (scene, launch shape) run kernel 9 twice (the first, on freshly allocated buffers, only warms up; the
+ * second is timed) and kernel 8 once (timed; rt_render waits for the three), and the following ones the faster of the
+ * two.  If a later launch of the chosen kernel takes more than 1.3x longer or shorter than its trial did — the camera
+ * turned, another tenant arrived — the two timed trials are repeated.  The choice belongs to the uploaded scene and the launch shape:
  * rt_update_instances keeps it (an animated scene is not re-measured every frame; after 256 updates it is), another
  * rt_upload_scene, launch shape, wavefront budget or tuning restarts it.  If kernel 9's device memory cannot be
  * allocated, the automatic choice settles on kernel 8 instead of failing, and when kernel 8 wins the trial kernel 9's

@@ -59,6 +59,7 @@ template <typename T> struct DevBuf {
 
 struct EventPair {
   hipEvent_t a, b;
+  bool watch = false; // a launch of the automatically chosen kernel: its time is checked for drift (rt_ctx::Tune)
 };
 
 } // namespace
@@ -122,9 +123,12 @@ struct rt_ctx {
   struct Tune {
     uint32_t key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t phase = 0; // 0 nothing measured, 1 kernel 9 measured, 2 both measured: `choice` holds
+    bool warmed = false; // kernel 9 has run once on this key's buffers (its first launch on fresh allocations is up to
+                         // 1.3x slower than its second: the timed trial is the second)
     float ms9 = 0.f, ms8 = 0.f;
     uint32_t choice = 9;
     uint32_t updates = 0; // rt_update_instances calls since the trial
+    float watched_ms = 0.f; // time of the most recent finished launch of the chosen kernel on this key (0 = none)
   } tune;
   // A measured choice belongs to an uploaded scene (`scene_epoch` counts rt_upload_scene) of a certain size (the bit
   // length of its pair count) and to a launch shape.  rt_update_instances — the reference's per-frame path when objects
@@ -149,6 +153,9 @@ int drain_events(rt_ctx *ctx) {
     HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
     ctx->last_ms = ms;
     ctx->total_ms += ms;
+    if (p.watch)
+      ctx->tune.watched_ms = ms;
+    p.watch = false;
     ctx->free_events.push_back(p);
   }
   ctx->pending.clear();
@@ -747,6 +754,7 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
   // either way.  The measurement is repeated when the scene, the instances or the launch shape change.
   uint32_t variant = ctx->variant;
   uint32_t tuning = 0; // 9 / 8: this launch is the timed trial of that kernel
+  bool paths_eligible = false; // this launch's kernel came from the measured choice
   if (ctx->variant_auto) {
     const uint64_t px = (uint64_t)pc.image_width * (pc.row_end - pc.row_begin) / (pc.row_group_stride > 1u ? pc.row_group_stride : 1u);
     // independent units of work the pipeline can keep in flight: samples (keyed PCG) or frames (Wang) per pixel
@@ -765,13 +773,30 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
         memcpy(ctx->tune.key, key, sizeof key);
         ctx->tune.phase = 0;
         ctx->tune.updates = 0;
+        ctx->tune.watched_ms = 0.f;
+        ctx->tune.warmed = false;
+      }
+      // Drift: the camera, a moved instance or another tenant can change what the launch costs without
+      // changing its key.  If the launch before this one ran the chosen kernel on this key and its time — known without
+      // waiting: its events have completed — is off the trial's by more than 1.3x, the trial is repeated.
+      if (ctx->tune.phase == 2) {
+        if (!ctx->pending.empty()) { // finished launches give up their times; a running one is not waited for
+          if (hipEventQuery(ctx->pending.back().b) == hipSuccess)
+            (void)drain_events(ctx);
+          else
+            (void)hipGetLastError(); // (hipErrorNotReady)
+        }
+        const float was = ctx->tune.choice == 9u ? ctx->tune.ms9 : ctx->tune.ms8, now = ctx->tune.watched_ms;
+        if (was > 0.f && now > 0.f && (now > 1.3f * was || was > 1.3f * now))
+          ctx->tune.phase = 0;
+        ctx->tune.watched_ms = 0.f;
       }
       if (ctx->tune.phase == 0)
-        variant = tuning = 9u;
+        variant = 9u, tuning = ctx->tune.warmed ? 9u : 1u; // (1: kernel 9's untimed first launch)
       else if (ctx->tune.phase == 1)
         variant = per_frame, tuning = 8u;
       else
-        variant = ctx->tune.choice == 9u ? 9u : per_frame;
+        variant = ctx->tune.choice == 9u ? 9u : per_frame, paths_eligible = true;
     } else
       variant = per_frame;
   }
@@ -785,7 +810,7 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
         return prc;
       (void)hipGetLastError();
       release_wavefront(ctx);
-      ctx->tune.phase = 2, ctx->tune.choice = 8u, ctx->tune.ms9 = ctx->tune.ms8 = 0.f;
+      ctx->tune.phase = 2, ctx->tune.choice = 8u, ctx->tune.ms9 = ctx->tune.ms8 = 0.f, ctx->tune.warmed = false;
       variant = (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u, tuning = 0u, wavefront = false;
     }
   }
@@ -813,18 +838,24 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
   }
   ctx->last_kernel = variant & 0xFFu;
   rc = end_timed(ctx, ev);
+  if (rc == RT_OK && ctx->variant_auto && !tuning && ctx->tune.phase == 2 && (wavefront || (variant & 0xFFu) == 8u || (variant & 0xFFu) == 0u))
+    ctx->pending.back().watch = paths_eligible; // (only launches that went through the measured choice)
   if (rc == RT_OK && tuning) { // a trial launch: wait for it and keep its time
     if ((rc = drain_events(ctx)) != RT_OK)
       return rc;
-    if (tuning == 9u) {
+    if (tuning == 1u) {
+      ctx->tune.warmed = true;
+    } else if (tuning == 9u) {
       ctx->tune.ms9 = (float)ctx->last_ms;
       ctx->tune.phase = 1;
     } else {
       ctx->tune.ms8 = (float)ctx->last_ms;
       ctx->tune.choice = ctx->tune.ms9 <= ctx->tune.ms8 ? 9u : 8u;
       ctx->tune.phase = 2;
-      if (ctx->tune.choice == 8u) // kernel 9 lost: its gigabytes of path state go back to the device
+      if (ctx->tune.choice == 8u) { // kernel 9 lost: its gigabytes of path state go back to the device
         release_wavefront(ctx);
+        ctx->tune.warmed = false;
+      }
     }
   }
   return rc;

@@ -109,7 +109,7 @@ def test_frame_batch_argument_checks(ctx):
 def test_c3_reference_rng_frame_batch_takes_the_wavefront_pipeline():
     """The reference's own configuration of the RNG — Wang hash, ONE sample per pixel per frame (Renderer.cpp:21, 625),
     high sample counts by progressive frames — on the C3 scene at 1920x1080: 24 frames in one call.  The automatic
-    choice times kernel 9 and the frame-by-frame megakernel once each and keeps the faster; every image equals the
+    choice warms kernel 9 up, times it and the frame-by-frame megakernel once each and keeps the faster; every image equals the
     others and, on three 8-row groups, the oracle's 24 sequential frames."""
     import bench
     w, h, depth, frames = 1920, 1080, 8, 24
@@ -121,15 +121,15 @@ def test_c3_reference_rng_frame_batch_takes_the_wavefront_pipeline():
     r.set_option(R.OPT_KERNEL_VARIANT, _ffi.KERNEL_VARIANT_AUTO)
     st = _ffi.Stats()
     imgs, kernels = [], []
-    for _ in range(3):
+    for _ in range(4):
         r.reset_accumulation()
         r.render_frames(cam, frames)
         assert r.frame_index == frames
         imgs.append(r.read_image())
         _ffi._check(_ffi.lib().rt_get_stats(C.c_void_p(r.hip_context_handle()), C.byref(st)))
         kernels.append(st.last_kernel)
-    assert kernels[:2] == [9, 8] and kernels[2] in (8, 9), kernels
-    assert _same(imgs[0], imgs[1]) and _same(imgs[0], imgs[2])
+    assert kernels[:3] == [9, 9, 8] and kernels[3] in (8, 9), kernels
+    assert all(_same(imgs[0], im) for im in imgs[1:])
     sa, camu = r.scene_arrays(), r.camera_uniforms(cam)
     want = _oracle_frames(sa, camu, w, h, 0, frames, 1, depth, T.RNG_WANG, row_begin=0, row_end=h, row_group_stride=67)
     rows = sharding.interleaved_rows(0, 67, h)

@@ -21,7 +21,7 @@ def measure(r, cam, spp, depth, frames=3):
     r.set_option(R.OPT_RNG_MODE, 1 if RNG == "pcg" else 0)
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, spp)
     r.set_option(R.OPT_MAX_DEPTH, depth)
-    for _ in range(3):  # warm-up; with RT_RNG=pcg the first two launches are the library's timed kernel trials
+    for _ in range(4):  # warm-up; with RT_RNG=pcg the first three launches are the library's kernel trials
         r.render(cam)
     r.wait()
     ctx = C.c_void_p(r.hip_context_handle()); L = _ffi.lib()
