@@ -145,9 +145,13 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
  * takes per atomic (multiple of 64, default 256); once `finish_paths` paths or fewer are alive one kernel sees them
  * through to their ends (0 = never; default 768 per CU).  0xFFFFFFFF = default.  The image does not depend on any of them.
  * _counts: since rt_reset_stats — trace + shade rounds, rounds whose trace pass walked the list, rays suspended, paths handed to the
- * finishing kernel. */
+ * finishing kernel.
+ * _compaction: the shade pass keeps the paths of its 256 slots sorted — paths that go on first, oldest first, the new
+ * paths' camera rays behind them, dead slots last — so that a trace wave holds coherent rays (default on; 0 = every
+ * path stays in the slot of its lane, the round-2 layout).  The image does not depend on it either. */
 int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share,
                               uint32_t finish_paths);
+int rt_debug_wavefront_compaction(rt_ctx *ctx, uint32_t enable);
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths);
 

@@ -51,6 +51,8 @@ struct rt_wf_tuning {
   uint32_t share = 0xFFFFFFFFu;         // slots a wave takes per atomic (a multiple of 64; default 256)
   uint32_t finish_paths = 0xFFFFFFFFu;  // once this many paths or fewer are alive one kernel sees them through, trace and
                                         // shade in a loop per lane (0 = never; default 768 per CU)
+  uint32_t compact = 0xFFFFFFFFu;       // the shade pass moves the paths that go on to the front of their 256-slot window
+                                        // and the new paths behind them (0 = every path stays in its lane's slot; default on)
 };
 struct rt_wf_counts { // statistics, summed over launches
   uint64_t rounds = 0;      // trace + shade rounds

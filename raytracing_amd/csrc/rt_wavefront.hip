@@ -49,6 +49,9 @@ namespace {
 // Atomics execute at the L2 per cache line, so the stripes of one counter sit WF_PAD words (256 B) apart: counters
 // packed into one line serialise like a single address.
 #define WF_STRIPES 64u
+#ifndef WF_SHADE_BLOCK
+#define WF_SHADE_BLOCK 256 // lanes of a k_wf_shade workgroup = slots of its window
+#endif
 #define WF_PAD 64u
 enum : uint32_t {
   // live paths after a shade pass, per stripe (summed by the host; the lengths of the live-slot list's segments).
@@ -114,10 +117,13 @@ __device__ __forceinline__ uint32_t wf_wang_seed(const rt_render_params &pc, uin
 // workgroup's position in its share lives in b.block_pos[blockIdx], touched by one thread per round.  Ids on tile
 // padding outside the image are skipped (the lane draws again).  Returns true for lanes that wrote a camera ray.
 // Must be called by all threads of the workgroup.
+// The new path's ray is handed back in new_o / new_d (and its Wang state in new_seed): the caller stores it where the
+// path is to live (k_wf_shade: the compacted position).
 template <bool WANG>
 __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, const rt_render_params &pc,
-                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, uint32_t slot) {
-  __shared__ uint32_t s_cnt[RT_BLOCK / 64], s_base;
+                                              const WfChunk &ch, const rt_wf_buffers &b, bool want, float4 &new_o,
+                                              float4 &new_d, uint32_t &new_seed) {
+  __shared__ uint32_t s_cnt[WF_SHADE_BLOCK / 64], s_base;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
   const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
@@ -129,7 +135,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
     __syncthreads();
     uint32_t before = 0, total = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) {
+    for (uint32_t w = 0; w < WF_SHADE_BLOCK / 64; ++w) {
       before += w < wave ? s_cnt[w] : 0u;
       total += s_cnt[w];
     }
@@ -156,17 +162,15 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
           if (WANG) { // entry = frame: its first sample; the state goes on through the frame's bounces and samples
             rng.seed = wf_wang_seed(pc, x, y, entry);
             camera_ray(cam, recip_sqrt_spp, x, y, 0u, 0u, rng, p);
-            b.seed[slot] = rng.seed;
-            if (spp > 1u)
-              b.fsum[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+            new_seed = rng.seed;
           } else {      // entry = frame * spp + sample: the absolute sample index keys the draws
             const uint32_t sample = entry % spp;
             rng.sample = pc.frame_index * spp + entry;
             rng.set_slot(0);
             camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
           }
-          b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
-          b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
+          new_o = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
+          new_d = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
           want = false; // (attenuation 1 and sample radiance +0: WF_HAS_ATT / WF_HAS_RAD clear, nothing to store)
           started = true;
         }
@@ -178,23 +182,47 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
 }
 
 // ---------------------------------------------------------------------------
-// k_wf_shade: lane i owns path slot i for the whole chunk (no lists, no compaction: while the chunk has ids left
-// every slot is refilled the moment its path ends, so all slots stay busy; only the last rounds thin out).  All state
-// traffic is coalesced.  INIT: nothing to shade, every slot just starts a path (the first fill of a chunk).
+// k_wf_shade: one lane per path slot; workgroup w works on the WINDOW of slots [w * 256, w * 256 + 256) for the whole
+// chunk (no global lists, no global compaction: while the chunk has ids left every slot is refilled the moment its
+// path ends, so all slots stay busy; only the last rounds thin out).  INIT: nothing to shade, every slot just starts a
+// path (the first fill of a chunk).
+//
+// Where a path lives inside its window is free — a ray's trace does not depend on the lane that runs it — and the
+// pass uses that (pass bit 30, "compaction"): the paths that go on are written to the front of the window in lane
+// order, the camera rays of the new paths behind them, dead slots last.  A trace wave works through a window from its
+// front (one share = one window), so it first holds scattered rays only and then the new paths' camera rays, which
+// are the pixels of one or two 8x8 tiles at one sample: 64 coherent rays step through the same records in the same
+// states (the triangle section of the step loop runs for all of them at once instead of for a dozen lanes), where the
+// in-place scheme mixed 28 of them with 36 scattered rays in every wave.  All loads of the window happen before the
+// first barrier and all stores after it; a wave's stores are runs of consecutive slots, so the traffic stays coalesced.
+// Slots that cannot move keep their place: suspended rays (the pool record names the slot) and the slots beyond
+// ch.slots in the last window.  Without the bit (and for the reference's RNG at spp > 1, whose per-slot sample sum
+// would have to move along) every path stays in the slot of its lane.
 // ---------------------------------------------------------------------------
 template <bool INIT, bool WANG>
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(WF_SHADE_BLOCK)
     k_wf_shade(rt_dev_scene sc, rt_camera_uniforms cam, rt_render_params pc, rt_wf_buffers b, WfChunk ch, uint32_t pass) {
-  const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+  constexpr uint32_t WAVES = WF_SHADE_BLOCK / 64;
+  __shared__ uint32_t s_on[WAVES], s_pin[WAVES], s_new[WAVES], s_dead[WAVES], s_live[WAVES], s_at;
+  __shared__ uint16_t s_free[WF_SHADE_BLOCK];
+  __shared__ uint8_t s_was_dead[WF_SHADE_BLOCK];
+  const uint32_t base = blockIdx.x * WF_SHADE_BLOCK, slot = base + threadIdx.x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
   const bool in_range = slot < ch.slots;
-  bool ended = false, goes_on = false;
+  const bool compact = (pass & 0x40000000u) != 0u;
+  bool ended = false, goes_on = false, pinned = !in_range, was_dead = false;
+  // what a path that goes on leaves in its slot
+  float4 out_o = make_float4(0.f, 0.f, 0.f, 0.f), out_d = out_o, out_a = out_o, out_r = out_o, out_fs = out_o;
+  bool put_att = false, put_rad = false, put_fs = false;
+  uint32_t out_seed = 0;
   if (INIT) {
     ended = in_range;
   } else if (in_range) {
     const float4 rd = b.ray_d[slot];
     uint32_t depth = __float_as_uint(rd.w);
     if (depth != WF_DEAD && (depth & WF_SUSPENDED)) {
-      goes_on = true; // the ray is still being traced (k_wf_trace resumes it next round): nothing to shade yet
+      goes_on = pinned = true; // the ray is still being traced (k_wf_trace resumes it next round): nothing to shade yet
     } else if (depth != WF_DEAD) {
       const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
       depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
@@ -221,15 +249,14 @@ __global__ void __launch_bounds__(RT_BLOCK)
       const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
       ++depth;
       if (scattered && depth < pc.max_depth) {
-        const bool keep_rad = (__float_as_uint(p.sample_radiance.x) | __float_as_uint(p.sample_radiance.y) |
-                               __float_as_uint(p.sample_radiance.z)) != 0u; // anything but +0, +0, +0
-        b.ray_o[slot] = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
-        b.ray_d[slot] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth | WF_HAS_ATT | (keep_rad ? WF_HAS_RAD : 0u)));
-        b.att[slot] = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f);
-        if (keep_rad)
-          b.rad[slot] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
-        if (WANG)
-          b.seed[slot] = rng.seed;
+        put_rad = (__float_as_uint(p.sample_radiance.x) | __float_as_uint(p.sample_radiance.y) |
+                   __float_as_uint(p.sample_radiance.z)) != 0u; // anything but +0, +0, +0
+        out_o = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
+        out_d = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth | WF_HAS_ATT | (put_rad ? WF_HAS_RAD : 0u)));
+        out_a = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f), put_att = true;
+        if (put_rad)
+          out_r = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        out_seed = rng.seed;
         goes_on = true;
       } else if (WANG) { // the sample ended: RayTracing.slang:170 in the slot, then the frame's next sample or its end
         const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -244,10 +271,10 @@ __global__ void __launch_bounds__(RT_BLOCK)
           ++s_idx;
           Path np;
           camera_ray(cam, 1.f / (float)pc.sqrt_spp, x, y, s_idx % pc.sqrt_spp, s_idx / pc.sqrt_spp, rng, np);
-          b.ray_o[slot] = make_float4(np.o.x, np.o.y, np.o.z, ro.w);
-          b.ray_d[slot] = make_float4(np.d.x, np.d.y, np.d.z, __uint_as_float(0u));
-          b.seed[slot] = rng.seed;
-          b.fsum[slot] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx));
+          out_o = make_float4(np.o.x, np.o.y, np.o.z, ro.w);
+          out_d = make_float4(np.d.x, np.d.y, np.d.z, __uint_as_float(0u));
+          out_seed = rng.seed;
+          out_fs = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx)), put_fs = true; // (spp > 1: no compaction)
           goes_on = true;
         } else {
           b.sr[id] = make_float4(sum.x, sum.y, sum.z, 0.f); // the frame's radiance
@@ -257,26 +284,81 @@ __global__ void __launch_bounds__(RT_BLOCK)
         b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
         ended = true;
       }
+    } else {
+      was_dead = true;
     }
   }
-  const bool started = wf_regenerate<WANG>(cam, pc, ch, b, ended, slot);
-  if (ended && !started)
-    b.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
+  // ---- the paths that go on: to the front of the window (every load of the window above, every store below) ----
+  const bool moves_on = goes_on && !pinned;
+  const unsigned long long m_on = __ballot(moves_on), m_pin = __ballot(pinned);
+  if (lane == 0)
+    s_on[wave] = (uint32_t)__popcll(m_on), s_pin[wave] = (uint32_t)__popcll(m_pin);
+  s_was_dead[threadIdx.x] = was_dead ? 1 : 0;
+  __syncthreads();
+  uint32_t on_before = 0, on_total = 0, pin_before = 0, pin_total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < WAVES; ++w) {
+    on_before += w < wave ? s_on[w] : 0u, on_total += s_on[w];
+    pin_before += w < wave ? s_pin[w] : 0u, pin_total += s_pin[w];
+  }
+  const bool direct = !compact || pin_total == 0u; // position k of the window is slot base + k
+  if (compact && pin_total != 0u) { // (uniform) the k-th slot that may be written: s_free[k]
+    if (!pinned)
+      s_free[threadIdx.x - pin_before - (uint32_t)__popcll(m_pin & below)] = (uint16_t)threadIdx.x;
+    __syncthreads();
+  }
+  auto place = [&](uint32_t k) { return !compact ? slot : direct ? base + k : base + s_free[k]; };
+  uint32_t dst = slot; // where this lane's path lives after the pass
+  if (moves_on) {
+    dst = place(on_before + (uint32_t)__popcll(m_on & below));
+    b.ray_o[dst] = out_o;
+    b.ray_d[dst] = out_d;
+    if (put_att)
+      b.att[dst] = out_a;
+    if (put_rad)
+      b.rad[dst] = out_r;
+    if (WANG)
+      b.seed[dst] = out_seed;
+    if (put_fs)
+      b.fsum[dst] = out_fs;
+  }
+  // ---- new paths behind them, dead slots last ----
+  float4 new_o = make_float4(0.f, 0.f, 0.f, 0.f), new_d = new_o;
+  uint32_t new_seed = 0;
+  const bool started = wf_regenerate<WANG>(cam, pc, ch, b, ended, new_o, new_d, new_seed);
+  const bool dead = !pinned && !moves_on && !started; // ended without a successor, or dead before
+  const unsigned long long m_new = __ballot(started), m_dead = __ballot(dead);
+  if (lane == 0)
+    s_new[wave] = (uint32_t)__popcll(m_new), s_dead[wave] = (uint32_t)__popcll(m_dead);
   // Live paths after this pass: one atomic per workgroup on its stripe's counter (the host sums the stripes), and what
   // the atomic returns places the workgroup's live slots in the stripe's segment of the live-slot list, which the
   // trace pass walks instead of the slots once most of them are dead.
-  __shared__ uint32_t s_live[RT_BLOCK / 64], s_at;
   const bool live = goes_on || started;
   const unsigned long long lm = __ballot(live);
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (lane == 0)
     s_live[wave] = (uint32_t)__popcll(lm);
   __syncthreads();
-  uint32_t before = 0, total = 0;
+  uint32_t new_before = 0, new_total = 0, dead_before = 0, before = 0, total = 0;
 #pragma unroll
-  for (uint32_t w = 0; w < RT_BLOCK / 64; ++w) {
-    before += w < wave ? s_live[w] : 0u;
-    total += s_live[w];
+  for (uint32_t w = 0; w < WAVES; ++w) {
+    new_before += w < wave ? s_new[w] : 0u, new_total += s_new[w];
+    dead_before += w < wave ? s_dead[w] : 0u;
+    before += w < wave ? s_live[w] : 0u, total += s_live[w];
+  }
+  if (started) {
+    dst = place(on_total + new_before + (uint32_t)__popcll(m_new & below));
+    b.ray_o[dst] = new_o;
+    b.ray_d[dst] = new_d;
+    if (WANG) {
+      b.seed[dst] = new_seed;
+      if (pc.sqrt_spp > 1u)
+        b.fsum[dst] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+    }
+  } else if (dead) {
+    dst = place(on_total + new_total + dead_before + (uint32_t)__popcll(m_dead & below));
+    // (a position that was dead before the pass needs no second mark: without compaction that is the lane's own)
+    if (!s_was_dead[dst - base])
+      b.ray_d[dst] = make_float4(0.f, 0.f, 0.f, __uint_as_float(WF_DEAD));
   }
   if (total == 0)
     return; // uniform over the workgroup
@@ -285,7 +367,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
     s_at = atomicAdd(b.ctrl + wf_alive_set(pass) + stripe * WF_PAD, total);
   __syncthreads();
   if (live && (pass >> 31)) // (bit 31: the host wants the list — not while every slot is refilled anyway)
-    b.live[(size_t)stripe * ch.list_span + s_at + before + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = slot;
+    b.live[(size_t)stripe * ch.list_span + s_at + before + (uint32_t)__popcll(lm & below)] = dst;
 }
 
 // ---------------------------------------------------------------------------
@@ -722,7 +804,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
     p.attenuation = v3(at4.x, at4.y, at4.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
     const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
     const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
-    const uint32_t blk = slot / RT_BLOCK; // the shade workgroup that owns the slot, and its share of the ids
+    const uint32_t blk = slot / WF_SHADE_BLOCK; // the shade workgroup that owns the slot, and its share of the ids
     // Wang: the pixel's RNG state and the frame's radiance so far travel with the slot
     uint32_t seed = 0, s_idx = 0;
     V3 sum = v3(0.f, 0.f, 0.f);
@@ -858,7 +940,7 @@ uint32_t rt_wf_pool_records(uint32_t cus) { // one record per lane of every trac
 
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records) {
   return (size_t)slots * (6 * sizeof(float4) + sizeof(float) + sizeof(uint32_t)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) + 2 * 256 +
-         ((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t) + ((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t) +
+         ((size_t)slots / WF_SHADE_BLOCK + 1) * sizeof(uint32_t) + ((size_t)slots + (size_t)(WF_STRIPES + 1) * WF_SHADE_BLOCK) * sizeof(uint32_t) +
          (size_t)2 * pool_records * WF_REC_WORDS * sizeof(uint32_t) +
          (size_t)tile_slots * sizeof(float4) + 16 * 256;
 }
@@ -881,8 +963,8 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
   b.seed = reinterpret_cast<uint32_t *>(take((size_t)slots * sizeof(uint32_t)));
   b.fsum = reinterpret_cast<float4 *>(take((size_t)slots * sizeof(float4)));
   b.partial = reinterpret_cast<float4 *>(take((size_t)tile_slots * sizeof(float4)));
-  b.block_pos = reinterpret_cast<uint32_t *>(take(((size_t)slots / RT_BLOCK + 1) * sizeof(uint32_t)));
-  b.live = reinterpret_cast<uint32_t *>(take(((size_t)slots + (size_t)(WF_STRIPES + 1) * RT_BLOCK) * sizeof(uint32_t)));
+  b.block_pos = reinterpret_cast<uint32_t *>(take(((size_t)slots / WF_SHADE_BLOCK + 1) * sizeof(uint32_t)));
+  b.live = reinterpret_cast<uint32_t *>(take(((size_t)slots + (size_t)(WF_STRIPES + 1) * WF_SHADE_BLOCK) * sizeof(uint32_t)));
   b.pool = reinterpret_cast<uint32_t *>(take((size_t)2 * pool_records * WF_REC_WORDS * sizeof(uint32_t)));
   b.pool_records = pool_records;
   b.slots = slots;
@@ -943,10 +1025,13 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS, false>), dim3(blocks), dim3(RT_BLOCK),     \
                          lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                            \
   } while (0)
-  auto span64 = [](uint64_t total) { // per-band share, a multiple of 64
+  auto span64 = [](uint64_t total) { // per-band share, whole windows of the shade pass (so that a share is one window)
     const uint64_t per = (total + WF_STRIPES - 1) / WF_STRIPES;
-    return (uint32_t)((per + 63) / 64 * 64);
+    return (uint32_t)((per + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK * WF_SHADE_BLOCK);
   };
+  // in-window compaction of the shade pass (k_wf_shade); not for the reference's RNG at spp > 1, whose per-slot sample
+  // sum would have to move with the path
+  const uint32_t compact_bit = tune.compact != 0u && !(wang && pc.sqrt_spp > 1u) ? 0x40000000u : 0u;
   hipError_t e;
   // measurement mode: an event before and after every dispatch, read back when the launch has drained
   struct Stamp {
@@ -994,7 +1079,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
     if (ch.slots > b.slots)
       ch.slots = b.slots / 64u * 64u;
     ch.slot_span = span64(ch.slots);
-    ch.list_span = ((ch.slots + RT_BLOCK - 1) / RT_BLOCK + WF_STRIPES - 1) / WF_STRIPES * RT_BLOCK;
+    ch.list_span = ((ch.slots + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK + WF_STRIPES - 1) / WF_STRIPES * WF_SHADE_BLOCK;
     ch.per_frame = wang ? 1u : pc.sqrt_spp * pc.sqrt_spp;
     const bool first = s0 == 0, last = s0 + ch.cs == spp;
     if (pc.max_depth == 0) { // no bounce is traced: every sample contributes nothing (RayTracing.slang:92)
@@ -1003,15 +1088,15 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
     } else {
       if ((e = hipMemsetAsync(b.ctrl, 0, RT_WF_CTRL_WORDS * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
-      const uint32_t shade_blocks = (ch.slots + RT_BLOCK - 1) / RT_BLOCK;
+      const uint32_t shade_blocks = (ch.slots + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK;
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
       stamp_begin(counts ? &counts->fill_ms : nullptr);
       if (wang)
-        hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+        hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
       else
-        hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch, 0u);
+        hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
       stamp_end();
       bool have_list = false; // the last shade pass wrote the live-slot list
       bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
@@ -1075,11 +1160,11 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         stamp_end();
         stamp_begin(counts ? &counts->shade_ms : nullptr);
         if (wang)
-          hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
-                             (round + 1u) | (make_list ? 0x80000000u : 0u));
+          hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                             ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
         else
-          hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(RT_BLOCK), 0, stream, sc, cam, pc, b, ch,
-                             (round + 1u) | (make_list ? 0x80000000u : 0u));
+          hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                             ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
         stamp_end();
         have_list = make_list;
         if ((e = hipGetLastError()) != hipSuccess)

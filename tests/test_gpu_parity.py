@@ -606,6 +606,50 @@ def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, li
         c.close()
 
 
+@pytest.mark.parametrize("rng,spp_side,frames", [(T.RNG_PCG, 3, 1), (T.RNG_WANG, 1, 7), (T.RNG_WANG, 2, 3)])
+@pytest.mark.parametrize("slots,suspend", [(8192, 0xFFFFFFFF), (8256, 64), (4160, 16)])
+def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slots, suspend):
+    """The shade pass of kernel 9 re-orders the paths of every 256-slot window (those that go on, the new camera rays,
+    the dead) so that trace waves hold coherent rays.  Which slot a path lives in must not matter: with the
+    re-ordering and without it the image is the oracle's bit for bit and the ray count the same — also when slots are
+    pinned (suspended rays: `suspend` 64 gives every wave's last rays up), when the last window is only partly inside
+    the slot space (8256 = 32 windows + 64 slots) and for the reference's RNG, whose state and — at spp > 1, where the
+    re-ordering is off by design — per-slot sample sum ride along."""
+    c = _ffi.HipContext(0)
+    try:
+        sc = S.mixed_scene().build()
+        w, h = 136, 76
+        from raytracing_amd import renderer as R
+        cam = R.Renderer(w, h, device=None).camera_uniforms(R.Camera((3.5, 2.5, 4.5), (0, 0, 0), (0, 1, 0), 45.0))
+        c.upload_scene(sc)
+        c.set_kernel_variant(9)
+        c.set_wavefront_budget(slots, 1 << 30)
+        c.wavefront_tuning(suspend, 75, 256, 300)
+        c.set_camera(cam)
+        c.resize(w, h)
+        p = O.render_params(w, h, 2, spp_side, 8, rng_mode=rng, accum_count=0)
+        want = np.zeros((h, w, 4), np.float32)
+        cn = O.Counters()
+        for f in range(frames):
+            q = O.render_params(w, h, 2 + f, spp_side, 8, rng_mode=rng)
+            q.accum_count = f
+            O.render(sc, cam, q, want, counters=cn, nthreads=8)
+        images, rays = [], []
+        for on in (True, False):
+            c.wavefront_compaction(on)
+            c.clear_accum()
+            c.reset_stats()
+            c.render_frames(p, frames)
+            images.append(c.read_accum(w, h))
+            rays.append(c.stats().rays_traced)
+            assert c.stats().last_kernel == 9
+        assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+        _same_image(images[0], want)
+        assert rays[0] == rays[1] == cn.rays
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("coop", [0, 1])
 def test_wavefront_deep_stack_and_edge_scenes(ctx, coop):
     """Kernel 9's trace kernel keeps 16 stack entries in LDS: the 38-instance chain drives it to 37; scenes outside the
