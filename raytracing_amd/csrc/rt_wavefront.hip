@@ -104,6 +104,15 @@ __device__ __forceinline__ void wf_pixel_of(const rt_render_params &pc, const Wf
   y = rt_row(pc, (tile / ch.tiles_x) * 8u + (in >> 3));
 }
 
+// Path id number p of workgroup blk's share of the chunk's ids: ids go out in groups of 64 (one 8x8 tile at one entry),
+// the workgroup's j-th group is group blk + j * blocks of the chunk — its paths are spread over the whole image (equal
+// work).  (Runs of 2 / 4 / 8 consecutive groups per workgroup, which keep a window's paths in one place of the scene:
+// trace time unchanged, shade +2 ... 6 %, measured in round 3 — locality between the rays of a window is not what the
+// trace pass lacks.)
+__device__ __forceinline__ uint64_t wf_share_id(uint32_t blk, uint32_t blocks, uint32_t p) {
+  return ((uint64_t)blk + (uint64_t)(p >> 6) * blocks) * 64u + (p & 63u);
+}
+
 // Seed of the reference's RNG for frame `frame` of the launch (RayTracing.slang:71-72 with frame_index + frame).
 __device__ __forceinline__ uint32_t wf_wang_seed(const rt_render_params &pc, uint32_t x, uint32_t y, uint32_t frame) {
   return (x * 1973u) ^ (y * 9277u) ^ ((pc.frame_index + frame) * 26699u);
@@ -149,7 +158,7 @@ __device__ __forceinline__ bool wf_regenerate(const rt_camera_uniforms &cam, con
     __syncthreads();
     if (want) {
       const uint32_t p = s_base + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      const uint64_t id64 = ((uint64_t)blockIdx.x + (uint64_t)(p >> 6) * gridDim.x) * 64u + (p & 63u);
+      const uint64_t id64 = wf_share_id(blockIdx.x, gridDim.x, p);
       if (id64 >= ch.total) {
         want = false; // the workgroup's share is used up (later positions lie even further out)
       } else {
@@ -848,7 +857,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
       bool started = false;
       while (true) {
         const uint32_t q = atomicAdd(b.block_pos + blk, 1u);
-        const uint64_t id64 = ((uint64_t)blk + (uint64_t)(q >> 6) * shade_blocks) * 64u + (q & 63u);
+        const uint64_t id64 = wf_share_id(blk, shade_blocks, q);
         if (id64 >= ch.total)
           break;
         id = (uint32_t)id64;
