@@ -16,10 +16,11 @@
 // Path state lives in HBM between the kernels (84 B per slot, millions of slots: the design leans on MI355X's HBM
 // capacity and bandwidth instead of registers).  A path is the pair (pixel, sample); path ids run tile-major —
 // id = (tile * chunk_samples + sample) * 64 + pixel_in_tile — so consecutive ids are the 64 pixels of one 8x8 tile:
-// the camera rays a wave starts together are coherent, and the resolve kernel reads its samples coalesced.  A slot
-// belongs to one lane of the shade kernel for the whole chunk: when its path ends the lane starts the next path in
-// place (ids from striped counters), so there are no lists and no compaction, the state traffic of the shade kernel
-// is coalesced, and every round traces about `slots` rays until the chunk runs out.
+// the camera rays a wave starts together are coherent, and the resolve kernel reads its samples coalesced.  A window
+// of 256 slots belongs to one workgroup of the shade kernel for the whole chunk: when a path ends the workgroup
+// starts the next one of its own share of the ids, so there are no global lists and no global compaction, the state
+// traffic of the shade kernel is coalesced, and every round traces about `slots` rays until the chunk runs out.
+// Inside its window the shade pass keeps the paths ordered (those that go on, then the new camera rays: k_wf_shade).
 // Per pixel the arithmetic, the RNG keys and the order of the radiance sum are those of k_render_v0 in PCG mode, so
 // the image is the same bit for bit.
 //
