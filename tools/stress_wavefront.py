@@ -35,13 +35,14 @@ for seed in range(500, 500 + cases):
         paths = w * h * sqrt_spp * sqrt_spp
         for rep in range(3):
             c.set_kernel_variant(9)
-            budget = int(rng.choice([4096, 1 << 16, 1 << 18, 1 << 20, 1 << 26]))
+            budget = int(rng.choice([4096, 4096 + 64, (1 << 16) + 192, 1 << 18, 1 << 20, 1 << 26]))  # (+64 / +192: a partly filled last window)
             tuning = (int(rng.choice([0, 4, 32, 64])), int(rng.choice([0, 50, 75, 100])), int(rng.choice([64, 256, 1024])),
                       int(rng.choice([0, 1000, 200000, 1 << 30])))
             if rep == 0:
                 tuning = (0xFFFFFFFF,) * 4
             c.set_wavefront_budget(budget, 10 << 30)
             c.wavefront_tuning(*tuning)
+            c.wavefront_compaction(rep != 2 or bool(rng.integers(0, 2)))  # ordered windows (default) / paths stay in place
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, nf)
