@@ -982,8 +982,12 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
 
 #define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per workgroup
 // the cooperative-fetch build: 12 KiB of stacks + 16.25 KiB of staging per workgroup, 5 workgroups per CU
+#ifndef RT_WF_COOP_MINW
 #define RT_WF_COOP_MINW 5
+#endif
+#ifndef RT_WF_COOP_NLDS
 #define RT_WF_COOP_NLDS 12
+#endif
 
 uint64_t rt_wf_entries(const rt_render_params &pc, uint32_t frame_count) {
   return pc.rng_mode == RT_RNG_WANG ? (uint64_t)frame_count : (uint64_t)frame_count * pc.sqrt_spp * pc.sqrt_spp;
