@@ -148,10 +148,15 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
  * finishing kernel.
  * _compaction: the shade pass keeps the paths of its 256 slots sorted — paths that go on first, oldest first, the new
  * paths' camera rays behind them, dead slots last — so that a trace wave holds coherent rays (default on; 0 = every
- * path stays in the slot of its lane, the round-2 layout).  The image does not depend on it either. */
+ * path stays in the slot of its lane, the round-2 layout).  The image does not depend on it either.
+ * _record_cache: the trace kernel copies the first 320 pair records — the breadth-first top of the scene, which every
+ * ray walks through — into LDS once per workgroup (512 lanes) and lanes at such a record read it there instead of
+ * gathering it through the L1 (default on; 0 = every record through the L1, workgroups of 256 lanes, the shape of
+ * rounds 2 and 3).  The image does not depend on it. */
 int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share,
                               uint32_t finish_paths);
 int rt_debug_wavefront_compaction(rt_ctx *ctx, uint32_t enable);
+int rt_debug_wavefront_record_cache(rt_ctx *ctx, uint32_t enable);
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths);
 

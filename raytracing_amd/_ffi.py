@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_render_frames", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_compaction", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_debug_wavefront_timing", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_compaction", "rt_debug_wavefront_record_cache", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_debug_wavefront_timing", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
@@ -99,6 +99,7 @@ def lib():
     L.rt_build_tlas_cluster_noalloc.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
     L.rt_debug_wavefront_tuning.argtypes = [vp, u32, u32, u32, u32]
     L.rt_debug_wavefront_compaction.argtypes = [vp, u32]
+    L.rt_debug_wavefront_record_cache.argtypes = [vp, u32]
     L.rt_debug_wavefront_counts.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.rt_debug_fail_wavefront_allocs.argtypes = [vp, u32]
     L.rt_debug_wavefront_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -246,6 +247,9 @@ class HipContext:
 
     def wavefront_compaction(self, enable=True):
         _check(lib().rt_debug_wavefront_compaction(self._h, 1 if enable else 0))
+
+    def wavefront_record_cache(self, enable=True):
+        _check(lib().rt_debug_wavefront_record_cache(self._h, 1 if enable else 0))
 
     def wavefront_tuning(self, suspend_lanes=0xFFFFFFFF, list_percent=0xFFFFFFFF, share=0xFFFFFFFF, finish_paths=0xFFFFFFFF):
         _check(lib().rt_debug_wavefront_tuning(self._h, suspend_lanes, list_percent, share, finish_paths))

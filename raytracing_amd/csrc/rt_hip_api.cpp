@@ -1029,6 +1029,14 @@ int rt_debug_wavefront_compaction(rt_ctx *ctx, uint32_t enable) {
   return RT_OK;
 }
 
+int rt_debug_wavefront_record_cache(rt_ctx *ctx, uint32_t enable) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_record_cache: NULL context");
+  ctx->wf_tuning.record_cache = enable ? 0xFFFFFFFFu : 0u;
+  ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old setting
+  return RT_OK;
+}
+
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths) {
   if (!ctx || !rounds || !list_rounds || !suspended_rays || !finished_paths)

@@ -53,6 +53,8 @@ struct rt_wf_tuning {
                                         // shade in a loop per lane (0 = never; default 768 per CU)
   uint32_t compact = 0xFFFFFFFFu;       // the shade pass moves the paths that go on to the front of their 256-slot window
                                         // and the new paths behind them (0 = every path stays in its lane's slot; default on)
+  uint32_t record_cache = 0xFFFFFFFFu;  // the trace kernel keeps the first pair records (the breadth-first top of the scene)
+                                        // in LDS, workgroups of 512 lanes (0 = every record through the L1, 256 lanes; default on)
 };
 struct rt_wf_counts { // statistics, summed over launches
   uint64_t rounds = 0;      // trace + shade rounds

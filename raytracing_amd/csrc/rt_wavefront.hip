@@ -413,7 +413,7 @@ enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
 #define WF_COOP_STRIDE 1040u
 #define WF_COOP_BYTES (4u * WF_COOP_STRIDE) // per wave
 
-template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP>
+template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP, int NCACHE>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_wf_trace(rt_dev_scene sc, rt_wf_geom geom, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter,
                uint32_t regen_idle, uint32_t sched_arg, uint32_t susp_arg) {
@@ -428,6 +428,19 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   const uint32_t stage_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32_ptr)stage_words);
   const lds_f4_ptr my_rec = (lds_f4_ptr)(lds_u32_ptr)(stage_words + (lane & 3u) * (WF_COOP_STRIDE / 4u) + (lane >> 2) * 16u);
   const uint32_t sub16 = (lane & 3u) * 16u;
+  // NCACHE: the first records of the pair array — the breadth-first top of the scene (rt_hip_api.cpp), which every ray
+  // walks through — copied to LDS behind the stacks once per workgroup; a pair step of a lane whose record is among
+  // them reads LDS instead of gathering through the L1 (WF_CACHE above the kernel).
+  static_assert(!(COOP && NCACHE), "the staging area and the record cache share the space behind the stacks");
+  const uint32_t n_cached = NCACHE ? (sc.cache_pairs < (uint32_t)NCACHE ? sc.cache_pairs : (uint32_t)NCACHE) : 0u;
+  const uint32_t cache_lds = (uint32_t)(uintptr_t)(lds_u32_ptr)(lds_raw + NLDS * BLOCK);
+  if (NCACHE) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.pairs);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw + NLDS * BLOCK);
+    for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += BLOCK)
+      dst[i] = src[i];
+    __syncthreads();
+  }
 
   uint32_t state = WT_FETCH, slot = 0, traced = 0;
   V3 wo = v3(0.f, 0.f, 0.f), wd = v3(0.f, 0.f, 0.f); // the ray in world space
@@ -680,22 +693,51 @@ __global__ void __launch_bounds__(BLOCK, MINW)
                           ((uint64_t)(ref & 0x7FFFFFFFu) * stride + (base - (uint64_t)(uintptr_t)sc.pairs));
           const unsigned long long m1 = __ballot(do1), m13 = __ballot(act != 0u);
           unsigned long long saved;
-          asm volatile("; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)\n\t"
-                       "s_mov_b64 %[sv], exec\n\t"
-                       "s_mov_b64 exec, %[m13]\n\t"
-                       "global_load_dwordx4 %[a], %[q], off\n\t"
-                       "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
-                       "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
-                       "s_mov_b64 exec, %[m1]\n\t"
-                       "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
-                       "s_mov_b64 exec, %[sv]\n\t"
-                       "; RT_V8_LOADS_END"
-                       : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
-                       : [q] "v"(q), [m13] "s"(m13), [m1] "s"(m1)
-                       : "memory");
+          if (NCACHE) {
+            // lanes whose pair record sits in the LDS copy read it from there: the same destination registers, disjoint
+            // lanes (a load writes only the lanes of its EXEC), both kinds in flight until the consumers' waits
+            const unsigned long long mc = __ballot(do1 && ref < n_cached);
+            const unsigned long long g13 = m13 & ~mc, g1 = m1 & ~mc;
+            const uint32_t la = cache_lds + (ref << 6);
+            asm volatile("; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[g13]\n\t"
+                         "global_load_dwordx4 %[a], %[q], off\n\t"
+                         "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
+                         "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
+                         "s_mov_b64 exec, %[g1]\n\t"
+                         "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
+                         "s_mov_b64 exec, %[mc]\n\t"
+                         "ds_read_b128 %[a], %[la]\n\t"
+                         "ds_read_b128 %[b], %[la] offset:16\n\t"
+                         "ds_read_b128 %[c], %[la] offset:32\n\t"
+                         "ds_read_b64 %[d], %[la] offset:48\n\t"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         "; RT_V8_LOADS_END"
+                         : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
+                         : [q] "v"(q), [la] "v"(la), [g13] "s"(g13), [g1] "s"(g1), [mc] "s"(mc)
+                         : "memory");
+          } else {
+            asm volatile("; RT_V8_LOADS_BEGIN (tools/check_v8_asm.py)\n\t"
+                         "s_mov_b64 %[sv], exec\n\t"
+                         "s_mov_b64 exec, %[m13]\n\t"
+                         "global_load_dwordx4 %[a], %[q], off\n\t"
+                         "global_load_dwordx4 %[b], %[q], off offset:16\n\t"
+                         "global_load_dwordx4 %[c], %[q], off offset:32\n\t"
+                         "s_mov_b64 exec, %[m1]\n\t"
+                         "global_load_dwordx2 %[d], %[q], off offset:48\n\t"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         "; RT_V8_LOADS_END"
+                         : [a] "=&v"(qx), [b] "=&v"(qy), [c] "=&v"(qz), [d] "=&v"(qr), [sv] "=&s"(saved)
+                         : [q] "v"(q), [m13] "s"(m13), [m1] "s"(m1)
+                         : "memory");
+          }
         }
         if (do3) { // one triangle of the leaf: TriangleGeom::hit, Triangle.slang:6-42 (branch-free form, see k_render_v8)
-          asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_TRI" : "+v"(qx), "+v"(qy), "+v"(qz));
+          if (NCACHE) // (also the LDS reads of the pair lanes: they write other lanes of the same registers)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0) ; RT_V8_WAIT_TRI" : "+v"(qx), "+v"(qy), "+v"(qz));
+          else
+            asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_TRI" : "+v"(qx), "+v"(qy), "+v"(qz));
           if (__float_as_uint(qy.w))
             do_pop = true;
           else
@@ -717,7 +759,10 @@ __global__ void __launch_bounds__(BLOCK, MINW)
           hit_tri = accept ? __float_as_uint(qx.w) : hit_tri, hit_inst = accept ? cur_inst : hit_inst;
         }
         if (do1) {
-          asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
+          if (NCACHE)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0) ; RT_V8_WAIT_PAIR" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
+          else
+            asm volatile("s_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qr));
           const float4 px = make_float4(qx.x, qx.y, qx.z, qx.w), py = make_float4(qy.x, qy.y, qy.z, qy.w),
                        pz = make_float4(qz.x, qz.y, qz.z, qz.w), pr = make_float4(qr.x, qr.y, 0.f, 0.f);
           float dist1, dist2;
@@ -943,6 +988,7 @@ __global__ void __launch_bounds__(RT_BLOCK)
 #ifndef RT_WF_MINW
 #define RT_WF_MINW 6 // resident waves per SIMD the trace kernel is built for
 #endif
+#define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per 256 lanes
 
 uint32_t rt_wf_pool_records(uint32_t cus) { // one record per lane of every trace wave that can be resident
   return cus * RT_WF_MINW * 4u * 64u;
@@ -980,7 +1026,6 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
   b.slots = slots;
 }
 
-#define RT_WF_NLDS 16 // stack entries per lane in LDS: 16 KiB per workgroup
 // the cooperative-fetch build: 12 KiB of stacks + 16.25 KiB of staging per workgroup, 5 workgroups per CU
 #ifndef RT_WF_COOP_MINW
 #define RT_WF_COOP_MINW 5
@@ -991,6 +1036,31 @@ void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t 
 
 uint64_t rt_wf_entries(const rt_render_params &pc, uint32_t frame_count) {
   return pc.rng_mode == RT_RNG_WANG ? (uint64_t)frame_count : (uint64_t)frame_count * pc.sqrt_spp * pc.sqrt_spp;
+}
+
+// Workgroup shape of the trace kernel (per-lane fetch): lanes, stack entries per lane in LDS, records of the LDS copy
+// of the scene's breadth-first top.  Measured on C3 (256 spp, ms per launch; experiments/r03_lds_cache/ has all nine
+// shapes and the counters): 256 / 16 / none 242.0 (rounds 2 and 3), 256 / 16 / 160 237.5, 512 / 16 / 320 236.8,
+// 768 / 16 / 448 236.7, 768 / 12 / 640 236.5; larger workgroups or 12 stack entries without the copy: 242.0.  The copy
+// takes 28 % of the L1 accesses and 11 % of the L2 requests away and buys 2 %: the step is bound by its slowest lane's
+// miss, not by the access rate.  Three workgroups of 512 lanes per CU: 3 x (32 + 20) KiB of the 160 KiB of LDS.
+struct WfTraceShape {
+  uint32_t block, nlds, ncache;
+};
+#define WF_TRACE_BLOCK 512
+#define WF_TRACE_CACHE 320
+template <int MODE, int BLOCK, int NLDS, int NCACHE, typename... Args>
+static hipError_t wf_launch_trace_shape(uint32_t blocks, hipStream_t stream, Args... args) {
+  const size_t lds_bytes = (size_t)NLDS * BLOCK * 4 + (size_t)NCACHE * 64;
+  static_assert((size_t)NLDS * BLOCK * 4 + (size_t)NCACHE * 64 <= 65536, "more needs hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, BLOCK, NLDS, false, NCACHE>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
+  return hipSuccess;
+}
+template <int MODE, typename... Args>
+static hipError_t wf_launch_trace(const WfTraceShape &s, uint32_t blocks, hipStream_t stream, Args... args) {
+  if (s.ncache)
+    return wf_launch_trace_shape<MODE, WF_TRACE_BLOCK, RT_WF_NLDS, WF_TRACE_CACHE>(blocks, stream, args...);
+  return wf_launch_trace_shape<MODE, RT_BLOCK, RT_WF_NLDS, 0>(blocks, stream, args...);
 }
 
 hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &geom, const rt_camera_uniforms &cam,
@@ -1027,17 +1097,19 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   const uint32_t full_share = tune.share == 0xFFFFFFFFu ? WF_GRAB : tune.share < 64u ? 64u : tune.share > 4096u ? 4096u : tune.share / 64u * 64u;
   const bool coop = (knobs & 0x8000u) != 0u; // knob bit 15: quad-cooperative fetch instead of per-lane gathers
   const uint32_t sched = ((knobs >> 16) & 0xFFFu) | ((knobs >> 31) ? 0x8000u : 0u) | (((knobs >> 28) & 7u) << 12);
-  const size_t lds_bytes = coop ? (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES
-                                : (size_t)RT_WF_NLDS * RT_BLOCK * 4;
-  const uint64_t resident = (uint64_t)cus * ((coop ? RT_WF_COOP_MINW : RT_WF_MINW) * 4u / (RT_BLOCK / 64u));
+  // workgroup shape of the trace kernel: lanes, stack entries in LDS, records of the LDS copy of the scene's top
+  const WfTraceShape shape = coop ? WfTraceShape{RT_BLOCK, RT_WF_COOP_NLDS, 0}
+                           : tune.record_cache != 0u ? WfTraceShape{WF_TRACE_BLOCK, RT_WF_NLDS, WF_TRACE_CACHE} : WfTraceShape{RT_BLOCK, RT_WF_NLDS, 0};
+  const uint32_t tblock = shape.block;
+  const uint64_t resident = (uint64_t)cus * ((coop ? RT_WF_COOP_MINW : RT_WF_MINW) * 4u / (tblock / 64u));
 #define RT_WF_TRACE(MODE)                                                                                              \
   do {                                                                                                                 \
-    if (coop)                                                                                                          \
-      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true>), dim3(blocks), dim3(RT_BLOCK), \
-                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                            \
-    else                                                                                                               \
-      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, RT_BLOCK, RT_WF_NLDS, false>), dim3(blocks), dim3(RT_BLOCK),     \
-                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                            \
+    if (coop) {                                                                                                        \
+      const size_t lds_bytes = (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES;              \
+      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true, 0>), dim3(blocks), dim3(RT_BLOCK), \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                      \
+    } else if ((e = wf_launch_trace<MODE>(shape, blocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp)) != hipSuccess) \
+      return e;                                                                                                        \
   } while (0)
   auto span64 = [](uint64_t total) { // per-band share, whole windows of the shade pass (so that a share is one window)
     const uint64_t per = (total + WF_STRIPES - 1) / WF_STRIPES;
@@ -1157,14 +1229,14 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         const bool by_list = have_list && alive * 100u < (uint64_t)ch.slots * list_below;
         // (a short list goes out in smaller shares, down to one ray per lane: the last rounds are a matter of latency)
         uint32_t share = full_share;
-        if (by_list && alive / (resident * (RT_BLOCK / 64u)) < share)
-          share = (uint32_t)(alive / (resident * (RT_BLOCK / 64u))) / 64u * 64u;
+        if (by_list && alive / (resident * (tblock / 64u)) < share)
+          share = (uint32_t)(alive / (resident * (tblock / 64u))) / 64u * 64u;
         share = share < 64u ? 64u : share;
         const uint64_t need = ((by_list ? alive : (uint64_t)ch.slots) + share - 1) / share; // one wave per share at least
-        const uint32_t blocks = (uint32_t)(need / (RT_BLOCK / 64) + 1 < resident ? need / (RT_BLOCK / 64) + 1 : resident);
+        const uint32_t blocks = (uint32_t)(need / (tblock / 64) + 1 < resident ? need / (tblock / 64) + 1 : resident);
         // rays may be suspended while the rounds are full (the next round comes anyway and carries them along); once
         // the paths thin out every ray is seen through, or the stragglers would add rounds of their own
-        const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * RT_BLOCK <= b.pool_records
+        const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * tblock <= b.pool_records
                                    ? susp_lanes : 0u) | ((round & 1u) << 8) | (by_list ? 0x200u : 0u) | ((round & 1u) << 10) | (share << 16);
         stamp_begin(counts ? &counts->trace_ms : nullptr);
         if (pc.aabb_mode == RT_AABB_RCP)

@@ -59,3 +59,21 @@ def test_vector_spills_are_caught(tmp_path):
 def test_a_missing_marker_is_caught(tmp_path):
     groups, errors = _run(tmp_path, "_Z11k_render_v8ILi0EEvv:\n\ts_endpgm\n")
     assert groups == 0 and errors
+
+
+# k_wf_trace with the LDS copy of the top records: the group also issues ds_read into the same registers, and the
+# consumers' waits must then cover lgkmcnt as well
+WITH_LDS = GOOD.replace("\t; RT_V8_LOADS_END", "\tds_read_b128 v[16:19], v70\n\tds_read_b128 v[12:15], v70 offset:16\n"
+                        "\tds_read_b128 v[8:11], v70 offset:32\n\tds_read_b64 v[44:45], v70 offset:48\n\t; RT_V8_LOADS_END") \
+    .replace("s_waitcnt vmcnt(0) ;", "s_waitcnt vmcnt(0) lgkmcnt(0) ;")
+
+
+def test_lds_reads_in_the_group_pass_with_both_counters_waited_for(tmp_path):
+    groups, errors = _run(tmp_path, WITH_LDS)
+    assert groups == 1 and errors == []
+
+
+def test_lds_reads_need_the_lgkm_wait(tmp_path):
+    bad = WITH_LDS.replace("s_waitcnt vmcnt(0) lgkmcnt(0) ; RT_V8_WAIT_PAIR", "s_waitcnt vmcnt(0) ; RT_V8_WAIT_PAIR")
+    groups, errors = _run(tmp_path, bad)
+    assert groups == 1 and len(errors) == 1 and "in-flight" in errors[0]

@@ -614,7 +614,8 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
     re-ordering and without it the image is the oracle's bit for bit and the ray count the same — also when slots are
     pinned (suspended rays: `suspend` 64 gives every wave's last rays up), when the last window is only partly inside
     the slot space (8256 = 32 windows + 64 slots) and for the reference's RNG, whose state and — at spp > 1, where the
-    re-ordering is off by design — per-slot sample sum ride along."""
+    re-ordering is off by design — per-slot sample sum ride along.  Likewise for WHERE a pair record is read from: the
+    trace kernel's LDS copy of the scene's top records (default) against every record through the L1."""
     c = _ffi.HipContext(0)
     try:
         sc = S.mixed_scene().build()
@@ -635,8 +636,9 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
             q.accum_count = f
             O.render(sc, cam, q, want, counters=cn, nthreads=8)
         images, rays = [], []
-        for on in (True, False):
+        for on, cache in ((True, True), (False, False), (True, False)):
             c.wavefront_compaction(on)
+            c.wavefront_record_cache(cache)  # the trace kernel's LDS copy of the top records (and its 512-lane workgroups)
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, frames)
@@ -644,8 +646,9 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
             rays.append(c.stats().rays_traced)
             assert c.stats().last_kernel == 9
         assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+        assert np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
         _same_image(images[0], want)
-        assert rays[0] == rays[1] == cn.rays
+        assert rays[0] == rays[1] == rays[2] == cn.rays
     finally:
         c.close()
 

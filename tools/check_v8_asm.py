@@ -46,11 +46,13 @@ def check(path):
         if "RT_V8_LOADS_BEGIN" in ln:
             groups += 1
             dest = set()
+            lds_reads = False  # the group also reads LDS: the consumers' waits must cover lgkmcnt too
             j = i + 1
             while "RT_V8_LOADS_END" not in lines[j]:
-                mm = re.match(r"\s*global_load_dwordx\d\s+(\S+),", lines[j])
+                mm = re.match(r"\s*(?:global_load_dwordx\d|ds_read_b\d+)\s+(\S+),", lines[j])  # (k_wf_trace: LDS copies of the top records)
                 if mm:
                     dest |= regs_of(mm.group(1))
+                    lds_reads |= "ds_read" in lines[j]
                 j += 1
             if len(dest) != 14:
                 errors.append(f"{kernel}: load group at line {i + 1} defines {len(dest)} registers, expected 14")
@@ -67,7 +69,10 @@ def check(path):
                     seen.add("tri")
                 if "RT_V8_WAIT_PAIR" in t:
                     seen.add("pair")
-                if code.startswith("s_waitcnt") and "vmcnt(0)" in code:
+                if ("RT_V8_WAIT_TRI" in t or "RT_V8_WAIT_PAIR" in t) and lds_reads and "lgkmcnt(0)" not in code:
+                    errors.append(f"{kernel}: line {k + 1}: the load group reads LDS too, but this consumer's wait leaves the "
+                                  f"in-flight ds_read results uncovered (no lgkmcnt(0)): {code}")
+                if code.startswith("s_waitcnt") and "vmcnt(0)" in code and (not lds_reads or "lgkmcnt(0)" in code):
                     waited = True
                 elif code and not code.startswith(".") and not waited and (vregs_in(code) & dest):
                     errors.append(f"{kernel}: line {k + 1} touches a register of the in-flight load group "

@@ -43,6 +43,7 @@ for seed in range(500, 500 + cases):
             c.set_wavefront_budget(budget, 10 << 30)
             c.wavefront_tuning(*tuning)
             c.wavefront_compaction(rep != 2 or bool(rng.integers(0, 2)))  # ordered windows (default) / paths stay in place
+            c.wavefront_record_cache(rep != 1 or bool(rng.integers(0, 2)))  # top records in LDS (default) / all through the L1
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, nf)
