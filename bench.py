@@ -573,7 +573,7 @@ def main():
             roofline["counter_source"] = (f"profiles/roofline_latest.json ({k['pmc_dir']}, rocprofv3 --pmc passes of tools/profile_pmc.sh "
                                           f"on this workload, commit {cdoc.get('commit')}); durations measured in this run")
             sh = cdoc["kernels"].get(f"{label}:k_wf_shade")
-            if kernel_id == 9 and sh and per_kernel:
+            if kernel_id == 9 and sh and per_kernel and per_kernel["k_wf_shade"] > 0:  # (the rounds mode: a shade kernel of its own)
                 # the shade pass streams the path state (wide coalesced 16-byte accesses: FETCH_SIZE x2 is the calibrated reading)
                 hb = (2 * sh["fetch_bytes_raw"] + sh["write_bytes"]) / (per_kernel["k_wf_shade"] * 1e-3) / 1e9
                 roofline["secondary"] = {"kernel": "k_wf_shade", "bound": "hbm", "kernel_ms": per_kernel["k_wf_shade"],

@@ -39,6 +39,7 @@ struct rt_wf_geom {
 };
 
 uint32_t rt_wf_pool_records(uint32_t cus);
+uint64_t rt_wf_persistent_slots(uint32_t cus); // path slots the persistent mode can use: a window per resident trace wave
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records);
 void rt_wf_carve(void *state_mem, uint32_t slots, uint64_t tile_slots, uint32_t pool_records, rt_wf_buffers &b);
 
@@ -53,6 +54,9 @@ struct rt_wf_tuning {
                                         // shade in a loop per lane (0 = never; default 768 per CU)
   uint32_t compact = 0xFFFFFFFFu;       // the shade pass moves the paths that go on to the front of their 256-slot window
                                         // and the new paths behind them (0 = every path stays in its lane's slot; default on)
+  uint32_t persistent = 0xFFFFFFFFu;    // no rounds: every trace wave owns a window of 512 slots and fills, traces and shades it
+                                        // in a loop (0 = rounds of trace and shade kernels with the host between them; 1 = always;
+                                        // default: for the keyed PCG RNG, rounds for the reference's)
   uint32_t record_cache = 0xFFFFFFFFu;  // the trace kernel keeps the first pair records (the breadth-first top of the scene)
                                         // in LDS, workgroups of 512 lanes (0 = every record through the L1, 256 lanes; default on)
 };

@@ -380,6 +380,217 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
     b.live[(size_t)stripe * ch.list_span + s_at + before + (uint32_t)__popcll(lm & below)] = dst;
 }
 
+
+// ---------------------------------------------------------------------------
+// PERSIST mode of k_wf_trace (EXPERIMENT): no rounds.  Every resident wave owns a window of WP_WINDOW path slots for the
+// whole launch and loops: fill the free positions with new paths (camera rays of whole 64-id groups, drawn from
+// striped counters), trace the window's rays (the step loop, lanes refilling from the window, stragglers suspended),
+// shade the window (one lane per slot, 64 at a time; paths that go on are written to the window's front in place).
+// The path state never leaves the wave, so it lives in L2 / the Infinity Cache instead of streaming through HBM
+// every round, there is no kernel boundary per round and the host never waits.
+// ---------------------------------------------------------------------------
+// slots per wave.  C3, 256 spp, ms per launch (full frame / one rank's eighth): 128 254.4 / 32.7, 256 232.7 / 30.4,
+// 512 226.6 / 29.9, 1024 225.2 / 31.7 — against 242.5 / 36.4 for the rounds (experiments/r03_persistent/)
+#define WP_WINDOW 512u
+#define WP_NO_GROUP 0xFFFFFFFFu
+struct WpState {
+  uint32_t base = 0;     // first slot of the wave's window
+  uint32_t n_on = 0;     // paths at the window's front that go on (after a shade)
+  uint32_t n_live = 0;   // slots in use (after a fill)
+  uint32_t stripe = 0;   // the striped group counter this wave draws from
+  uint32_t pend_group = 0;
+  unsigned long long pend_mask = 0;  // lanes of pend_group whose paths have not been started yet
+  unsigned long long used_seen = 0;  // stripes known to be used up
+  uint32_t ids_left = 1;
+};
+
+// the next group of 64 path ids (one 8x8 tile at one entry), or WP_NO_GROUP: stripe s hands out groups s, s + 64, ...
+__device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const WfChunk &ch, WpState &wp) {
+  const uint32_t groups = ch.total >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  while (true) {
+    const unsigned long long avail = ~wp.used_seen;
+    if (avail == 0ull)
+      return WP_NO_GROUP;
+    const unsigned long long rot = wp.stripe ? ((avail >> wp.stripe) | (avail << (64u - wp.stripe))) : avail;
+    wp.stripe = (wp.stripe + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
+    uint32_t k = 0;
+    if (lane == 0)
+      k = atomicAdd(b.ctrl + WF_HEAD + wp.stripe * WF_PAD, 1u);
+    k = (uint32_t)__builtin_amdgcn_readlane((int)k, 0);
+    const uint64_t g = (uint64_t)wp.stripe + (uint64_t)k * WF_STRIPES;
+    if (g < groups)
+      return (uint32_t)g;
+    wp.used_seen |= 1ull << wp.stripe;
+  }
+}
+
+template <bool WANG>
+__device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_render_params &pc, const WfChunk &ch,
+                                        const rt_wf_buffers &b, WpState &wp) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  const float recip_sqrt_spp = 1.f / (float)pc.sqrt_spp; // Renderer.cpp:628
+  uint32_t fill = wp.n_on;
+  while (fill < WP_WINDOW) {
+    if (wp.pend_mask == 0ull) {
+      if (!wp.ids_left)
+        break;
+      const uint32_t g = wp_draw_group(b, ch, wp);
+      if (g == WP_NO_GROUP) {
+        wp.ids_left = 0u;
+        break;
+      }
+      wp.pend_group = g;
+      uint32_t x, y, entry;
+      wf_pixel_of(pc, ch, g * 64u + lane, x, y, entry);
+      const unsigned long long m = __ballot(x < pc.image_width && y < pc.row_end); // (else tile padding)
+      wp.pend_mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) |
+                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32);
+      continue;
+    }
+    const uint32_t room = WP_WINDOW - fill;
+    const uint32_t rank = (uint32_t)__popcll(wp.pend_mask & below);
+    const bool go = ((wp.pend_mask >> lane) & 1ull) != 0ull && rank < room;
+    if (go) {
+      const uint32_t id = wp.pend_group * 64u + lane;
+      uint32_t x, y, entry;
+      wf_pixel_of(pc, ch, id, x, y, entry);
+      Rng rng = make_rng(pc, x, y);
+      Path p;
+      const uint32_t dst = wp.base + fill + rank;
+      if (WANG) { // entry = frame: its first sample; the state goes on through the frame's bounces and samples
+        rng.seed = wf_wang_seed(pc, x, y, entry);
+        camera_ray(cam, recip_sqrt_spp, x, y, 0u, 0u, rng, p);
+        b.seed[dst] = rng.seed;
+        if (spp > 1u)
+          b.fsum[dst] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+      } else {    // entry = frame * spp + sample: the absolute sample index keys the draws
+        const uint32_t sample = entry % spp;
+        rng.sample = pc.frame_index * spp + entry;
+        rng.set_slot(0);
+        camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
+      }
+      b.ray_o[dst] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
+      b.ray_d[dst] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
+    }
+    const unsigned long long went = __ballot(go);
+    fill += (uint32_t)__popcll(went);
+    wp.pend_mask &= ~went;
+    wp.pend_mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp.pend_mask) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp.pend_mask >> 32)) << 32);
+  }
+  wp.n_live = (uint32_t)__builtin_amdgcn_readfirstlane((int)fill);
+}
+
+// shades the window's traced rays, 64 slots at a time (the arithmetic of k_wf_shade); the paths that go on (and the
+// suspended rays, untouched) are written to the front of the window IN PLACE: position n_on + rank <= the slot being
+// read, and a batch's loads are complete before its stores.  Everything a path owns moves with it: ray, attenuation,
+// radiance, and — reference's RNG — its state and (spp > 1) the frame's sample sum; a suspended ray also takes the
+// index of its pool record (hit_v) along.
+template <bool WANG>
+__device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera_uniforms &cam, const rt_render_params &pc,
+                                         const rt_wf_buffers &b, const WfChunk &ch, WpState &wp) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
+  const bool sums = WANG && spp > 1u; // the slot carries the frame's radiance over the samples done so far
+  uint32_t n_on = 0;
+  for (uint32_t g0 = 0; g0 < wp.n_live; g0 += 64u) {
+    const uint32_t slot = wp.base + g0 + lane;
+    bool goes_on = false, put_att = false, put_rad = false, put_v = false;
+    float4 out_o = make_float4(0.f, 0.f, 0.f, 0.f), out_d = out_o, out_a = out_o, out_r = out_o, out_fs = out_o;
+    float out_v = 0.f;
+    uint32_t out_seed = 0;
+    if (g0 + lane < wp.n_live) {
+      const float4 rd = b.ray_d[slot];
+      uint32_t depth = __float_as_uint(rd.w);
+      const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
+      const float4 ro = b.ray_o[slot];
+      const float4 at = has_att ? b.att[slot] : make_float4(1.f, 1.f, 1.f, 0.f);
+      const float4 ra = has_rad ? b.rad[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (WANG)
+        out_seed = b.seed[slot];
+      if (sums)
+        out_fs = b.fsum[slot];
+      if (depth & WF_SUSPENDED) { // still being traced: moves along as it is, with the index of its pool record
+        goes_on = true;
+        out_o = ro, out_d = rd, out_a = at, out_r = ra, put_att = has_att, put_rad = has_rad;
+        out_v = b.hit_v[slot], put_v = true;
+      } else {
+        depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
+        const float4 h = b.hit[slot];
+        const uint32_t id = __float_as_uint(ro.w);
+        uint32_t x, y, entry;
+        wf_pixel_of(pc, ch, id, x, y, entry);
+        Rng rng = make_rng(pc, x, y);
+        if (WANG) {
+          rng.seed = out_seed; // the pixel's sequential state, where the bounce before left it
+        } else {
+          rng.sample = pc.frame_index * spp + entry;
+          rng.set_slot(depth + 1u);
+        }
+        Path p;
+        p.o = v3(ro.x, ro.y, ro.z), p.d = v3(rd.x, rd.y, rd.z);
+        p.attenuation = v3(at.x, at.y, at.z), p.sample_radiance = v3(ra.x, ra.y, ra.z);
+        Hit hit;
+        hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
+        const bool any = hit.tri != RT_INVALID_ID;
+        hit.v = any ? b.hit_v[slot] : 0.f;
+        const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
+        ++depth;
+        if (scattered && depth < pc.max_depth) {
+          put_rad = (__float_as_uint(p.sample_radiance.x) | __float_as_uint(p.sample_radiance.y) |
+                     __float_as_uint(p.sample_radiance.z)) != 0u; // anything but +0, +0, +0
+          out_o = make_float4(p.o.x, p.o.y, p.o.z, ro.w);
+          out_d = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(depth | WF_HAS_ATT | (put_rad ? WF_HAS_RAD : 0u)));
+          out_a = make_float4(p.attenuation.x, p.attenuation.y, p.attenuation.z, 0.f), put_att = true;
+          out_r = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+          out_seed = rng.seed;
+          goes_on = true;
+        } else if (WANG) { // the sample ended: RayTracing.slang:170 in the slot, then the frame's next sample or its end
+          V3 sum = v3(out_fs.x, out_fs.y, out_fs.z); // (+0 at spp 1)
+          uint32_t s_idx = __float_as_uint(out_fs.w);
+          sum = sum + p.sample_radiance;
+          if (s_idx + 1u < spp) { // the next sample of this pixel and frame continues the RNG stream (:76-77)
+            ++s_idx;
+            Path np;
+            camera_ray(cam, 1.f / (float)pc.sqrt_spp, x, y, s_idx % pc.sqrt_spp, s_idx / pc.sqrt_spp, rng, np);
+            out_o = make_float4(np.o.x, np.o.y, np.o.z, ro.w);
+            out_d = make_float4(np.d.x, np.d.y, np.d.z, __uint_as_float(0u));
+            out_seed = rng.seed;
+            out_fs = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx));
+            goes_on = true;
+          } else {
+            b.sr[id] = make_float4(sum.x, sum.y, sum.z, 0.f); // the frame's radiance
+          }
+        } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
+          b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+        }
+      }
+    }
+    const unsigned long long m_on = __ballot(goes_on);
+    if (goes_on) {
+      const uint32_t dst = wp.base + n_on + (uint32_t)__popcll(m_on & below);
+      b.ray_o[dst] = out_o;
+      b.ray_d[dst] = out_d;
+      if (put_att)
+        b.att[dst] = out_a;
+      if (put_rad)
+        b.rad[dst] = out_r;
+      if (put_v)
+        b.hit_v[dst] = out_v;
+      if (WANG)
+        b.seed[dst] = out_seed;
+      if (sums)
+        b.fsum[dst] = out_fs;
+    }
+    n_on += (uint32_t)__popcll(m_on);
+  }
+  wp.n_on = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_on);
+}
+
 // ---------------------------------------------------------------------------
 // k_wf_trace: persistent wave64s; a lane traces one ray at a time and takes the next live slot when it is done.  The
 // step loop is k_render_v8's (vote scheduling, joined pair / leaf steps, exact fast slab division); what a lane carries
@@ -413,10 +624,10 @@ enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
 #define WF_COOP_STRIDE 1040u
 #define WF_COOP_BYTES (4u * WF_COOP_STRIDE) // per wave
 
-template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP, int NCACHE>
+template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP, int NCACHE, bool PERSIST, bool WANG>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_wf_trace(rt_dev_scene sc, rt_wf_geom geom, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter,
-               uint32_t regen_idle, uint32_t sched_arg, uint32_t susp_arg) {
+               uint32_t regen_idle, uint32_t sched_arg, uint32_t susp_arg, rt_camera_uniforms cam, rt_render_params pc) {
   extern __shared__ __align__(16) uint32_t lds_raw[];
   uint32_t *lds_stack = lds_raw; // [NLDS][BLOCK]
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -469,8 +680,14 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   // bands this wave knows to be used up (those beyond the slot space from the start)
   const uint32_t n_bands = by_list ? WF_STRIPES : (ch.slots + ch.slot_span - 1u) / ch.slot_span;
   unsigned long long used_seen = n_bands >= 64u ? 0ull : ~((1ull << n_bands) - 1ull);
-  uint32_t *const pool_w = b.pool + (size_t)((susp_arg >> 8) & 1u) * b.pool_records * WF_REC_WORDS;
-  const uint32_t *const pool_r = b.pool + (size_t)(((susp_arg >> 8) & 1u) ^ 1u) * b.pool_records * WF_REC_WORDS;
+  // (PERSIST: a wave resumes in its next trace phase what it suspended in the last one — one pool)
+  uint32_t *const pool_w = b.pool + (PERSIST ? (size_t)0 : (size_t)((susp_arg >> 8) & 1u) * b.pool_records * WF_REC_WORDS);
+  const uint32_t *const pool_r = b.pool + (PERSIST ? (size_t)0 : (size_t)(((susp_arg >> 8) & 1u) ^ 1u) * b.pool_records * WF_REC_WORDS);
+  // PERSIST: the wave owns the window of WP_WINDOW slots at wp_base for the whole launch and alternates between
+  // filling it, tracing it and shading it (wp_fill / wp_shade below)
+  WpState wp;
+  wp.base = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * WP_WINDOW;
+  wp.stripe = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
 
   const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
   const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
@@ -479,6 +696,22 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   const uint32_t join_min = join_code == 0u ? 8u : join_code == 1u ? 1u : join_code == 2u ? 4u : join_code == 3u ? 6u
                           : join_code == 4u ? 12u : join_code == 5u ? 16u : join_code == 6u ? 24u : 65u;
 
+  if (PERSIST && blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6) >= share) // (PERSIST: bits 16-31 = windows of the launch)
+    return;
+  do { // (PERSIST: one turn per fill / trace / shade of the window; otherwise once)
+  if (PERSIST) {
+    wp_fill<WANG>(cam, pc, ch, b, wp);
+    if (wp.n_live == 0u)
+      break;
+    grab_next = wp.base, grab_end = wp.base + wp.n_live;
+    q_empty = 0u, steps = 0u, susp_min = susp_arg & 0xFFu;
+    // every lane starts the phase without a ray: nothing of the last phase is live (said explicitly, or the
+    // traversal state would occupy registers through the fill and the shade)
+    state = WT_FETCH, slot = 0;
+    wo = wd = co = cd = cinv = v3(0.f, 0.f, 0.f);
+    ref = RT_REF_NONE, cur_inst = 0, closest = hit_u = hit_v = 0.f, hit_tri = hit_inst = anyv = fastv = 0u;
+    st.sp = 0;
+  }
   while (true) {
     // ---- (1) finished rays: the hit record goes to the slot ----
     if (state == WT_FINISHED) {
@@ -493,7 +726,13 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       const unsigned long long mask = __ballot(need);
       if (mask == 0ull)
         break;
-      if (grab_next >= grab_end) { // the wave's share is used up: `share` more slots from a band head
+      if (PERSIST && grab_next >= grab_end) { // the window has been handed out
+        if (need)
+          state = WT_EXIT;
+        q_empty = 1u;
+        break;
+      }
+      if (!PERSIST && grab_next >= grab_end) { // the wave's share is used up: `share` more slots from a band head
         // which bands have slots left: one 64-bit word, a bit per band that a wave found used up (a look at the 64
         // heads themselves cost 64 reads at device scope per share, as much as the rounds' tails)
         // (looking only after the wave's own band has run out — one round trip per share instead of two — measured
@@ -826,6 +1065,9 @@ __global__ void __launch_bounds__(BLOCK, MINW)
       }
     }
   }
+  if (PERSIST)
+    wp_shade<WANG>(sc, cam, pc, b, ch, wp);
+  } while (PERSIST);
   count_rays(ray_counter, traced);
 }
 
@@ -994,6 +1236,10 @@ uint32_t rt_wf_pool_records(uint32_t cus) { // one record per lane of every trac
   return cus * RT_WF_MINW * 4u * 64u;
 }
 
+uint64_t rt_wf_persistent_slots(uint32_t cus) { // a window for every trace wave that can be resident
+  return (uint64_t)cus * RT_WF_MINW * 4u * WP_WINDOW;
+}
+
 size_t rt_wf_state_bytes(uint32_t slots, uint64_t tile_slots, uint32_t pool_records) {
   return (size_t)slots * (6 * sizeof(float4) + sizeof(float) + sizeof(uint32_t)) + RT_WF_CTRL_WORDS * sizeof(uint32_t) + 2 * 256 +
          ((size_t)slots / WF_SHADE_BLOCK + 1) * sizeof(uint32_t) + ((size_t)slots + (size_t)(WF_STRIPES + 1) * WF_SHADE_BLOCK) * sizeof(uint32_t) +
@@ -1053,7 +1299,14 @@ template <int MODE, int BLOCK, int NLDS, int NCACHE, typename... Args>
 static hipError_t wf_launch_trace_shape(uint32_t blocks, hipStream_t stream, Args... args) {
   const size_t lds_bytes = (size_t)NLDS * BLOCK * 4 + (size_t)NCACHE * 64;
   static_assert((size_t)NLDS * BLOCK * 4 + (size_t)NCACHE * 64 <= 65536, "more needs hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, BLOCK, NLDS, false, NCACHE>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
+  hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, BLOCK, NLDS, false, NCACHE, false, false>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
+  return hipSuccess;
+}
+template <int MODE, bool WANG, typename... Args>
+static hipError_t wf_launch_persist(uint32_t blocks, hipStream_t stream, Args... args) {
+  const size_t lds_bytes = (size_t)RT_WF_NLDS * WF_TRACE_BLOCK * 4 + (size_t)WF_TRACE_CACHE * 64;
+  hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, WF_TRACE_BLOCK, RT_WF_NLDS, false, WF_TRACE_CACHE, true, WANG>), dim3(blocks),
+                     dim3(WF_TRACE_BLOCK), lds_bytes, stream, args...);
   return hipSuccess;
 }
 template <int MODE, typename... Args>
@@ -1106,9 +1359,9 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
   do {                                                                                                                 \
     if (coop) {                                                                                                        \
       const size_t lds_bytes = (size_t)RT_WF_COOP_NLDS * RT_BLOCK * 4 + (RT_BLOCK / 64u) * WF_COOP_BYTES;              \
-      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true, 0>), dim3(blocks), dim3(RT_BLOCK), \
-                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp);                      \
-    } else if ((e = wf_launch_trace<MODE>(shape, blocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp)) != hipSuccess) \
+      hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_COOP_MINW, RT_BLOCK, RT_WF_COOP_NLDS, true, 0, false, false>), dim3(blocks), dim3(RT_BLOCK), \
+                         lds_bytes, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc);             \
+    } else if ((e = wf_launch_trace<MODE>(shape, blocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc)) != hipSuccess) \
       return e;                                                                                                        \
   } while (0)
   auto span64 = [](uint64_t total) { // per-band share, whole windows of the shade pass (so that a share is one window)
@@ -1177,6 +1430,35 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       const uint32_t shade_blocks = (ch.slots + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK;
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
+      // (default: for the keyed PCG RNG; the reference's RNG — 86 registers in its shade part, state and sample sum
+      // riding along — is faster through the rounds: 256 frames of C3 4945 against 4048 Mrays/s.  A budget below one
+      // window: the rounds.)
+      if ((tune.persistent == 0xFFFFFFFFu ? !wang : tune.persistent != 0u) && !coop && b.slots >= WP_WINDOW) {
+        // No rounds: one launch of the trace kernel in its PERSIST mode renders the chunk — every wave fills, traces
+        // and shades its own window of slots until the chunk's path ids are used up.  Nothing is read back, the host
+        // does not wait.
+        const uint64_t waves_max = (uint64_t)cus * RT_WF_MINW * 4u;
+        uint64_t waves = ((uint64_t)ch.total + WP_WINDOW - 1) / WP_WINDOW;
+        waves = waves < waves_max ? waves : waves_max;
+        if (waves * WP_WINDOW > b.slots)
+          waves = b.slots / WP_WINDOW;
+        const uint32_t pblocks = (uint32_t)((waves + WF_TRACE_BLOCK / 64 - 1) / (WF_TRACE_BLOCK / 64));
+        if (waves == 0 || waves > 0xFFFFu || (uint64_t)pblocks * WF_TRACE_BLOCK > b.pool_records)
+          return hipErrorInvalidValue;
+        const uint32_t susp = susp_lanes | ((uint32_t)waves << 16); // (one pool, no list; bits 16-31: windows)
+        stamp_begin(counts ? &counts->trace_ms : nullptr);
+#define RT_WF_PERSIST(MODE)                                                                                            \
+  (wang ? wf_launch_persist<MODE, true>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc)  \
+        : wf_launch_persist<MODE, false>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc))
+        e = pc.aabb_mode == RT_AABB_RCP ? RT_WF_PERSIST(RT_AABB_RCP) : RT_WF_PERSIST(RT_AABB_DIV);
+#undef RT_WF_PERSIST
+        stamp_end();
+        if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+          return e;
+        if (counts)
+          ++counts->rounds;
+        goto resolve_chunk;
+      }
       // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
       stamp_begin(counts ? &counts->fill_ms : nullptr);
       if (wang)
@@ -1262,6 +1544,7 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         }
       }
     }
+  resolve_chunk:
     stamp_begin(counts ? &counts->resolve_ms : nullptr);
     hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,
                        b, ch, (uint32_t)tile_slots, accum, first ? 1u : 0u, last ? 1u : 0u);

@@ -50,10 +50,19 @@ def test_a_copy_of_an_in_flight_register_is_caught(tmp_path):
     assert groups == 1 and len(errors) == 1 and "in-flight" in errors[0]
 
 
-def test_vector_spills_are_caught(tmp_path):
-    bad = GOOD.replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 3")
+def test_spill_traffic_inside_a_load_window_is_caught(tmp_path):
+    bad = GOOD.replace("\tv_mov_b32_e32 v63, v7\n", "\tscratch_store_dword off, v63, off offset:16 ; 4-byte Folded Spill\n") \
+        .replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 1")
     groups, errors = _run(tmp_path, bad)
-    assert any("vector register spills" in e for e in errors)
+    assert any("spill traffic" in e for e in errors)
+
+
+def test_spills_outside_the_load_windows_are_only_reported(tmp_path, capsys):
+    ok = GOOD.replace("\ts_mov_b64 s[10:11], exec\n", "\tscratch_store_dword off, v63, off offset:16 ; 4-byte Folded Spill\n\ts_mov_b64 s[10:11], exec\n") \
+        .replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 1")
+    groups, errors = _run(tmp_path, ok)
+    assert groups == 1 and errors == []
+    assert "vector register spills" in capsys.readouterr().out
 
 
 def test_a_missing_marker_is_caught(tmp_path):

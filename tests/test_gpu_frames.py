@@ -53,19 +53,24 @@ def test_frame_batch_equals_frames_one_by_one(ctx, rng_mode, sqrt_spp):
     want3 = _oracle_frames(sc, cam, w, h, 0, 3, sqrt_spp, depth, rng_mode)
     want10 = _oracle_frames(sc, cam, w, h, 3, 7, sqrt_spp, depth, rng_mode, img=want3.copy())
     assert not _same(want3, want10)
-    settings = [(0, None, None), (8, None, None), (9, None, None), (9, (4096, 1 << 20), None),
-                (9, (1 << 12, 5 << 18), (64, 100, 64, 0)), (9, (1 << 16, 1 << 24), (64, 100, 64, 1 << 30))]
-    for variant, budget, tuning in settings:
+    # (persistent: kernel 9 without rounds, the default; False = trace / shade rounds, to which the last three tuning values belong)
+    settings = [(0, None, None, True), (8, None, None, True), (9, None, None, True), (9, None, None, False),
+                (9, (4096, 1 << 20), None, True), (9, (4096, 1 << 20), None, False),
+                (9, (1 << 12, 5 << 18), (64, 100, 64, 0), False), (9, (1 << 12, 5 << 18), (64, 100, 64, 0), True),
+                (9, (1 << 16, 1 << 24), (64, 100, 64, 1 << 30), False)]
+    for variant, budget, tuning, persistent in settings:
         ctx.set_kernel_variant(variant)
         ctx.set_wavefront_budget(*(budget or (1 << 26, 40 << 30)))
         ctx.wavefront_tuning(*(tuning or (0xFFFFFFFF,) * 4))
+        ctx.wavefront_persistent(persistent)
         ctx.clear_accum()
         for f in range(3):
             ctx.render(O.render_params(w, h, f, sqrt_spp, depth, rng_mode=rng_mode))
-        assert _same(ctx.read_accum(w, h), want3), (variant, budget, tuning)
+        assert _same(ctx.read_accum(w, h), want3), (variant, budget, tuning, persistent)
         ctx.render_frames(O.render_params(w, h, 3, sqrt_spp, depth, rng_mode=rng_mode), 7)
         assert ctx.stats().last_kernel == variant
-        assert _same(ctx.read_accum(w, h), want10), (variant, budget, tuning)
+        assert _same(ctx.read_accum(w, h), want10), (variant, budget, tuning, persistent)
+    ctx.wavefront_persistent(None)
     ctx.wavefront_tuning()
     ctx.set_wavefront_budget(1 << 26, 40 << 30)
     ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)

@@ -561,12 +561,15 @@ def test_wavefront_small_budgets_many_rounds_and_chunks(slots, result_bytes):
                                                          (32, 75, 256, 0), (8, 50, 512, 300), (64, 100, 64, 3000),
                                                          (0, 100, 256, 1 << 30)])
 @pytest.mark.parametrize("scene", ["mixed", "chain"])
-def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, listp, share, finish):
+@pytest.mark.parametrize("persistent", [False, True])
+def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, listp, share, finish, persistent):
     """Kernel 9's round scheduling — trace waves that give their last rays up (traversal state saved to HBM, resumed
     next round, also from inside an instance and with stack entries beyond the LDS part) and trace passes that walk the
     list of live slots, and the kernel that sees the last paths through (from a few hundred left to everything after
     the first thinning round, new paths of unfinished shares included) — changes neither the image nor the ray count,
-    whatever the thresholds; the counters show that the paths under test were taken."""
+    whatever the thresholds; the counters show that the paths under test were taken.  `persistent`: the same settings
+    on the mode without rounds (the default), where only the suspension threshold applies — a wave gives the last rays
+    of its window up and resumes them in its next trace phase."""
     c = _ffi.HipContext(0)
     try:
         if scene == "mixed":
@@ -582,6 +585,7 @@ def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, li
         c.set_kernel_variant(9)
         c.set_wavefront_budget(8192, 1 << 30)  # 8 Ki slots for 93 K / 35 K paths: full rounds, then the thinning ones
         c.wavefront_tuning(suspend, listp, share, finish)
+        c.wavefront_persistent(persistent)
         c.set_camera(cam)
         c.resize(w, h)
         c.reset_stats()
@@ -592,10 +596,13 @@ def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, li
         _same_image(c.read_accum(w, h), want)
         assert c.stats().rays_traced == cn.rays  # a resumed ray is not counted twice
         rounds, list_rounds, suspended, finished = c.wavefront_counts()
-        assert rounds >= (8 if finish < (1 << 30) else 2)
-        if finish < (1 << 30):  # (with everything handed to the finisher no trace pass is left to walk the list)
-            assert (list_rounds > 0) == (listp > 0), (rounds, list_rounds)
-        assert (finished > 0) == (finish > 0), (rounds, finished)
+        if persistent:
+            assert (rounds, list_rounds, finished) == (1, 0, 0)  # one launch of the trace kernel per chunk, nothing else
+        else:
+            assert rounds >= (8 if finish < (1 << 30) else 2)
+            if finish < (1 << 30):  # (with everything handed to the finisher no trace pass is left to walk the list)
+                assert (list_rounds > 0) == (listp > 0), (rounds, list_rounds)
+            assert (finished > 0) == (finish > 0), (rounds, finished)
         assert (suspended > 0) == (suspend > 0), (rounds, suspended)
         # a second frame on top through the same state buffers, in two interleaved shards
         for rb in (0, 8):
@@ -636,9 +643,10 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
             q.accum_count = f
             O.render(sc, cam, q, want, counters=cn, nthreads=8)
         images, rays = [], []
-        for on, cache in ((True, True), (False, False), (True, False)):
+        for on, cache, persistent in ((True, True, False), (False, False, False), (True, False, False), (True, True, True)):
             c.wavefront_compaction(on)
             c.wavefront_record_cache(cache)  # the trace kernel's LDS copy of the top records (and its 512-lane workgroups)
+            c.wavefront_persistent(persistent)  # no rounds: every wave fills, traces and shades its own window (the default)
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, frames)
@@ -647,8 +655,9 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
             assert c.stats().last_kernel == 9
         assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
         assert np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
+        assert np.array_equal(images[0].view(np.uint32), images[3].view(np.uint32))
         _same_image(images[0], want)
-        assert rays[0] == rays[1] == rays[2] == cn.rays
+        assert rays[0] == rays[1] == rays[2] == rays[3] == cn.rays
     finally:
         c.close()
 

@@ -126,6 +126,8 @@ def test_random_scene_kernel9_round_scheduling_is_invisible(seed):
         tuning = (int(rng.choice([0, 4, 32, 64])), int(rng.choice([0, 50, 100])), int(rng.choice([64, 128, 256, 1024])),
                   int(rng.choice([0, 100, 5000, 1 << 30])))
         c.wavefront_tuning(*tuning)
+        persistent = bool(rng.integers(0, 2))  # no rounds (the default; budgets below one window of 512 slots fall back) / rounds
+        c.wavefront_persistent(persistent)
         c.reset_stats()
         cn = O.Counters()
         want = np.zeros((h, w, 4), np.float32)
@@ -134,7 +136,7 @@ def test_random_scene_kernel9_round_scheduling_is_invisible(seed):
             c.render(p)
             O.render(sc, cam, p, want, counters=cn, nthreads=8)
         got = c.read_accum(w, h)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, tuning, sqrt_spp, depth, aabb)
-        assert c.stats().rays_traced == cn.rays, (seed, tuning)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, tuning, persistent, sqrt_spp, depth, aabb)
+        assert c.stats().rays_traced == cn.rays, (seed, tuning, persistent)
     finally:
         c.close()

@@ -44,6 +44,8 @@ for seed in range(500, 500 + cases):
             c.wavefront_tuning(*tuning)
             c.wavefront_compaction(rep != 2 or bool(rng.integers(0, 2)))  # ordered windows (default) / paths stay in place
             c.wavefront_record_cache(rep != 1 or bool(rng.integers(0, 2)))  # top records in LDS (default) / all through the L1
+            persistent = rep == 0 or bool(rng.integers(0, 2))  # no rounds (default) / trace and shade rounds
+            c.wavefront_persistent(persistent)
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, nf)
@@ -52,7 +54,7 @@ for seed in range(500, 500 + cases):
             counts = c.wavefront_counts()
             ok = diff == 0 and rays9 == rays0
             bad += 0 if ok else 1
-            print(f"seed {seed} {w}x{h} rng {rng_mode} frames {nf} spp {sqrt_spp**2} depth {depth} paths {paths} budget {budget} tuning {tuning}: "
+            print(f"seed {seed} {w}x{h} rng {rng_mode} frames {nf} spp {sqrt_spp**2} depth {depth} paths {paths} budget {budget} tuning {tuning} {'persistent' if persistent else 'rounds'}: "
                   f"rounds/list/suspended/finished {counts} differing {diff} rays {rays9} vs {rays0} {'ok' if ok else 'MISMATCH'}", flush=True)
     finally:
         c.close()
