@@ -121,7 +121,8 @@ def product_layout_bytes_per_ray(cn, spp_per_launch):
     return (trav + shade) / rays, 32.0 / spp_per_launch
 
 
-KERNEL_NAMES = {0: "k_render_v0", 8: "k_render_v8", 9: "k_wf_trace + k_wf_shade + k_wf_resolve (kernel 9)"}
+KERNEL_NAMES = {0: "k_render_v0", 8: "k_render_v8",
+                9: "kernel 9: k_wf_trace in its persistent mode (every wave fills, traces and shades its window of path slots) + k_wf_resolve"}
 
 
 def host_threads(requested):

@@ -153,8 +153,7 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
  * ray walks through — into LDS once per workgroup (512 lanes) and lanes at such a record read it there instead of
  * gathering it through the L1 (default on; 0 = every record through the L1, workgroups of 256 lanes, the shape of
  * rounds 2 and 3).  The image does not depend on it.
- * _persistent: kernel 9 without rounds (1 = always, 0 = never, 0xFFFFFFFF = the default: for RT_RNG_PCG, while the
- * reference's RNG, whose shade part needs more registers, keeps the rounds) — one launch of the trace kernel in which every wave owns a window
+ * _persistent: kernel 9 without rounds (default on) — one launch of the trace kernel in which every wave owns a window
  * of 512 path slots and fills it with new paths, traces it and shades it in a loop until the launch's paths are used
  * up; the host reads nothing back, so rt_render returns at once as it does for kernels 0 and 8.  0 = the rounds of
  * rounds 2 and 3: a trace and a shade kernel per round over all slots, the host reading the live-path count between

@@ -250,8 +250,7 @@ class HipContext:
         _check(lib().rt_debug_wavefront_compaction(self._h, 1 if enable else 0))
 
     def wavefront_persistent(self, enable=True):
-        """True / False: always / never; None: the library's default (keyed PCG yes, the reference's RNG no)."""
-        _check(lib().rt_debug_wavefront_persistent(self._h, 0xFFFFFFFF if enable is None else 1 if enable else 0))
+        _check(lib().rt_debug_wavefront_persistent(self._h, 1 if enable else 0))
 
     def wavefront_record_cache(self, enable=True):
         _check(lib().rt_debug_wavefront_record_cache(self._h, 1 if enable else 0))

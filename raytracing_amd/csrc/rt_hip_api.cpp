@@ -400,8 +400,7 @@ int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc, uint32_t frame_co
   uint64_t want_slots = (chunk_paths / 6 + 255) / 256 * 256; // (a 6.6e7-path launch: 1/2 ... 1/8 level, 1/16 -20 %)
   if (want_slots < (1u << 20))
     want_slots = chunk_paths < (1u << 20) ? chunk_paths : (1u << 20);
-  if (ctx->wf_tuning.persistent == 0xFFFFFFFFu ? pc.rng_mode != RT_RNG_WANG : ctx->wf_tuning.persistent != 0u) {
-    // no rounds: a window of slots per resident trace wave, whatever the launch's size
+  if (ctx->wf_tuning.persistent != 0u) { // no rounds: a window of slots per resident trace wave, whatever the launch's size
     const uint64_t windows = rt_wf_persistent_slots(ctx->cus);
     want_slots = chunk_paths < windows ? (chunk_paths + 511) / 512 * 512 : windows;
   }
@@ -1037,7 +1036,7 @@ int rt_debug_wavefront_compaction(rt_ctx *ctx, uint32_t enable) {
 int rt_debug_wavefront_persistent(rt_ctx *ctx, uint32_t enable) {
   if (!ctx)
     return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_persistent: NULL context");
-  ctx->wf_tuning.persistent = enable == 0xFFFFFFFFu ? enable : enable ? 1u : 0u;
+  ctx->wf_tuning.persistent = enable ? 0xFFFFFFFFu : 0u;
   ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old setting
   return RT_OK;
 }

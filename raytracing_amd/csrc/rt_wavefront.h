@@ -55,8 +55,7 @@ struct rt_wf_tuning {
   uint32_t compact = 0xFFFFFFFFu;       // the shade pass moves the paths that go on to the front of their 256-slot window
                                         // and the new paths behind them (0 = every path stays in its lane's slot; default on)
   uint32_t persistent = 0xFFFFFFFFu;    // no rounds: every trace wave owns a window of 512 slots and fills, traces and shades it
-                                        // in a loop (0 = rounds of trace and shade kernels with the host between them; 1 = always;
-                                        // default: for the keyed PCG RNG, rounds for the reference's)
+                                        // in a loop (0 = rounds of trace and shade kernels with the host between them; default on)
   uint32_t record_cache = 0xFFFFFFFFu;  // the trace kernel keeps the first pair records (the breadth-first top of the scene)
                                         // in LDS, workgroups of 512 lanes (0 = every record through the L1, 256 lanes; default on)
 };

@@ -1302,11 +1302,21 @@ static hipError_t wf_launch_trace_shape(uint32_t blocks, hipStream_t stream, Arg
   hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, BLOCK, NLDS, false, NCACHE, false, false>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
   return hipSuccess;
 }
+// the persistent mode's shape: as the trace pass for the keyed PCG RNG; for the reference's RNG, whose shade part
+// needs 86 registers, 5 waves per SIMD in workgroups of 256 lanes (5 x (16 + 10) KiB of LDS per CU).  C3, 256 frames
+// of 1 spp: 6 waves (28 spills in the shade phase) 298 ms, 5 waves 236 ms, the rounds 240 ms; the keyed PCG RNG
+// in the 5-wave shape: 236 against 228 ms.
+#ifndef WP_WANG_MINW
+#define WP_WANG_MINW 5
+#endif
+#define WP_WANG_BLOCK 256
+#define WP_WANG_CACHE 160
 template <int MODE, bool WANG, typename... Args>
 static hipError_t wf_launch_persist(uint32_t blocks, hipStream_t stream, Args... args) {
-  const size_t lds_bytes = (size_t)RT_WF_NLDS * WF_TRACE_BLOCK * 4 + (size_t)WF_TRACE_CACHE * 64;
-  hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, WF_TRACE_BLOCK, RT_WF_NLDS, false, WF_TRACE_CACHE, true, WANG>), dim3(blocks),
-                     dim3(WF_TRACE_BLOCK), lds_bytes, stream, args...);
+  constexpr int BLOCK = WANG ? WP_WANG_BLOCK : WF_TRACE_BLOCK, CACHE = WANG ? WP_WANG_CACHE : WF_TRACE_CACHE;
+  const size_t lds_bytes = (size_t)RT_WF_NLDS * BLOCK * 4 + (size_t)CACHE * 64;
+  hipLaunchKernelGGL((k_wf_trace<MODE, WANG ? WP_WANG_MINW : RT_WF_MINW, BLOCK, RT_WF_NLDS, false, CACHE, true, WANG>), dim3(blocks),
+                     dim3(BLOCK), lds_bytes, stream, args...);
   return hipSuccess;
 }
 template <int MODE, typename... Args>
@@ -1430,20 +1440,19 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
       const uint32_t shade_blocks = (ch.slots + WF_SHADE_BLOCK - 1) / WF_SHADE_BLOCK;
       if ((e = hipMemsetAsync(b.block_pos, 0, (size_t)shade_blocks * sizeof(uint32_t), stream)) != hipSuccess)
         return e;
-      // (default: for the keyed PCG RNG; the reference's RNG — 86 registers in its shade part, state and sample sum
-      // riding along — is faster through the rounds: 256 frames of C3 4945 against 4048 Mrays/s.  A budget below one
-      // window: the rounds.)
-      if ((tune.persistent == 0xFFFFFFFFu ? !wang : tune.persistent != 0u) && !coop && b.slots >= WP_WINDOW) {
+      // (a budget below one window: the rounds)
+      if (tune.persistent != 0u && !coop && b.slots >= WP_WINDOW) {
         // No rounds: one launch of the trace kernel in its PERSIST mode renders the chunk — every wave fills, traces
         // and shades its own window of slots until the chunk's path ids are used up.  Nothing is read back, the host
         // does not wait.
-        const uint64_t waves_max = (uint64_t)cus * RT_WF_MINW * 4u;
+        const uint32_t pblock = wang ? WP_WANG_BLOCK : WF_TRACE_BLOCK;
+        const uint64_t waves_max = (uint64_t)cus * (wang ? WP_WANG_MINW : RT_WF_MINW) * 4u;
         uint64_t waves = ((uint64_t)ch.total + WP_WINDOW - 1) / WP_WINDOW;
         waves = waves < waves_max ? waves : waves_max;
         if (waves * WP_WINDOW > b.slots)
           waves = b.slots / WP_WINDOW;
-        const uint32_t pblocks = (uint32_t)((waves + WF_TRACE_BLOCK / 64 - 1) / (WF_TRACE_BLOCK / 64));
-        if (waves == 0 || waves > 0xFFFFu || (uint64_t)pblocks * WF_TRACE_BLOCK > b.pool_records)
+        const uint32_t pblocks = (uint32_t)((waves + pblock / 64 - 1) / (pblock / 64));
+        if (waves == 0 || waves > 0xFFFFu || (uint64_t)pblocks * pblock > b.pool_records)
           return hipErrorInvalidValue;
         const uint32_t susp = susp_lanes | ((uint32_t)waves << 16); // (one pool, no list; bits 16-31: windows)
         stamp_begin(counts ? &counts->trace_ms : nullptr);

@@ -70,7 +70,7 @@ def test_frame_batch_equals_frames_one_by_one(ctx, rng_mode, sqrt_spp):
         ctx.render_frames(O.render_params(w, h, 3, sqrt_spp, depth, rng_mode=rng_mode), 7)
         assert ctx.stats().last_kernel == variant
         assert _same(ctx.read_accum(w, h), want10), (variant, budget, tuning, persistent)
-    ctx.wavefront_persistent(None)
+    ctx.wavefront_persistent(True)
     ctx.wavefront_tuning()
     ctx.set_wavefront_budget(1 << 26, 40 << 30)
     ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
