@@ -89,7 +89,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params);
  * into the running mean (:176-179; ++frame_index, Renderer.cpp:651).  Frames params->frame_index + k are accumulated
  * as params->accum_count + k, k = 0 .. frame_count - 1: the image is that of frame_count successive rt_render calls,
  * bit for bit.  Handing the frames over together lets the library run them side by side: (pixel, frame) pairs are
- * independent also under the reference's sequential Wang RNG, so batches of at least 2e7 of them may go through the
+ * independent also under the reference's sequential Wang RNG, so batches of at least 2e6 of them may go through the
  * wavefront pipeline (kernel 9) — which a single frame of the reference's RNG cannot. */
 int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame_count);
 
@@ -115,7 +115,7 @@ int rt_reset_stats(rt_ctx *ctx);
  * run one after the other in a slot; rt_render blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
  * rt_launch_render).  All kernels give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new
  * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
- * depth 3 per launch (the reference's live configuration), and except launches of at least 2e7 independent units of
+ * depth 3 per launch (the reference's live configuration), and except launches of at least 2e6 independent units of
  * work — pixels x frames x samples under RT_RNG_PCG (1920x1080 from 10 samples per pixel on), pixels x frames under
  * RT_RNG_WANG (rt_render_frames from 10 frames on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
  * launches of a (scene, launch shape) run kernel 9 twice (the first, on freshly allocated buffers, only warms up; the

@@ -756,6 +756,10 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
   // instances 3.2 against 4.05 (tools/bench_configs.py, 1080p) — so an eligible shape is MEASURED: its first launch
   // runs kernel 9, its second kernel 8, and from the third on the faster of the two.  The images are the same bits
   // either way.  The measurement is repeated when the scene, the instances or the launch shape change.
+  // End of round 3: kernel 9 without rounds (rt_wavefront.hip, PERSIST) has no per-round costs left, and wins from ONE
+  // sample per pixel on (tools/bench_spp_sweep.py, 1080p, kernel 8 / kernel 9 in Mrays/s — C3: 1 spp 1531 / 1667, 4 spp
+  // 2111 / 3275, 16 spp 3397 / 4499, 64 spp 3586 / 5173; Cornell box 3971 / 4985, 4652 / 8282, 8021 / 9593, 8981 / 9979;
+  // teapot 3015 / 3257, 4376 / 7508, 5301 / 10928, 5818 / 13139): the threshold is now 2e6 paths, the choice still measured.
   uint32_t variant = ctx->variant;
   uint32_t tuning = 0; // 9 / 8: this launch is the timed trial of that kernel
   bool paths_eligible = false; // this launch's kernel came from the measured choice
@@ -767,7 +771,7 @@ int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame
     const uint32_t per_frame = (ctx->dev.cache_pairs <= 256u && pc.sqrt_spp <= 2u && pc.max_depth <= 3u) ? 0u : 8u;
     if (per_frame == 0u && frame_count == 1u)
       variant = 0u;
-    else if (pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 20000000ull) {
+    else if (pc.max_depth > 0u && pc.max_depth < (1u << 28) && paths >= 2000000ull) {
       uint32_t size_class = 0; // bit length of the pair count: instance edits keep it, another scene rarely does
       for (uint32_t n = ctx->pair_count; n; n >>= 1)
         ++size_class;

@@ -393,6 +393,23 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
 // 512 226.6 / 29.9, 1024 225.2 / 31.7 — against 242.5 / 36.4 for the rounds (experiments/r03_persistent/)
 #define WP_WINDOW 512u
 #define WP_NO_GROUP 0xFFFFFFFFu
+
+// Path-state accesses of the fill and shade phases are NON-TEMPORAL: the state of a window (43 KB) comes back to its
+// wave long after the L2 has forgotten it (768 windows per XCD against 4 MB), so caching it there only displaces node
+// records — with the persistent mode's shade phases running beside other waves' trace phases the L2 hit rate fell from
+// 65 to 57 %.  C3, 256 spp: 227.8 -> 220.6 ms with the hint on every state load and store here (on the loads and the
+// result stores only: 222.4; also on the trace phase's ray loads and hit stores: 223.0 — those stay plain).
+typedef float wp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wp_ld4(const float4 *p) {
+  wp_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wp_f4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wp_st4(float4 *p, float4 a) {
+  wp_f4 v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<wp_f4 *>(p));
+}
+__device__ __forceinline__ float wp_ld1(const float *p) { return __builtin_nontemporal_load(p); }
+
 struct WpState {
   uint32_t base = 0;     // first slot of the wave's window
   uint32_t n_on = 0;     // paths at the window's front that go on (after a shade)
@@ -472,8 +489,8 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
         rng.set_slot(0);
         camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
       }
-      b.ray_o[dst] = make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id));
-      b.ray_d[dst] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u));
+      wp_st4(b.ray_o + dst, make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id)));
+      wp_st4(b.ray_d + dst, make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u)));
     }
     const unsigned long long went = __ballot(go);
     fill += (uint32_t)__popcll(went);
@@ -504,12 +521,12 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
     float out_v = 0.f;
     uint32_t out_seed = 0;
     if (g0 + lane < wp.n_live) {
-      const float4 rd = b.ray_d[slot];
+      const float4 rd = wp_ld4(b.ray_d + slot);
       uint32_t depth = __float_as_uint(rd.w);
       const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
-      const float4 ro = b.ray_o[slot];
-      const float4 at = has_att ? b.att[slot] : make_float4(1.f, 1.f, 1.f, 0.f);
-      const float4 ra = has_rad ? b.rad[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 ro = wp_ld4(b.ray_o + slot);
+      const float4 at = has_att ? wp_ld4(b.att + slot) : make_float4(1.f, 1.f, 1.f, 0.f);
+      const float4 ra = has_rad ? wp_ld4(b.rad + slot) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (WANG)
         out_seed = b.seed[slot];
       if (sums)
@@ -520,7 +537,7 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
         out_v = b.hit_v[slot], put_v = true;
       } else {
         depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
-        const float4 h = b.hit[slot];
+        const float4 h = wp_ld4(b.hit + slot);
         const uint32_t id = __float_as_uint(ro.w);
         uint32_t x, y, entry;
         wf_pixel_of(pc, ch, id, x, y, entry);
@@ -537,7 +554,7 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
         Hit hit;
         hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
         const bool any = hit.tri != RT_INVALID_ID;
-        hit.v = any ? b.hit_v[slot] : 0.f;
+        hit.v = any ? wp_ld1(b.hit_v + slot) : 0.f;
         const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
         ++depth;
         if (scattered && depth < pc.max_depth) {
@@ -563,22 +580,22 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
             out_fs = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx));
             goes_on = true;
           } else {
-            b.sr[id] = make_float4(sum.x, sum.y, sum.z, 0.f); // the frame's radiance
+            wp_st4(b.sr + id, make_float4(sum.x, sum.y, sum.z, 0.f)); // the frame's radiance
           }
         } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
-          b.sr[id] = make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f);
+          wp_st4(b.sr + id, make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f));
         }
       }
     }
     const unsigned long long m_on = __ballot(goes_on);
     if (goes_on) {
       const uint32_t dst = wp.base + n_on + (uint32_t)__popcll(m_on & below);
-      b.ray_o[dst] = out_o;
-      b.ray_d[dst] = out_d;
+      wp_st4(b.ray_o + dst, out_o);
+      wp_st4(b.ray_d + dst, out_d);
       if (put_att)
-        b.att[dst] = out_a;
+        wp_st4(b.att + dst, out_a);
       if (put_rad)
-        b.rad[dst] = out_r;
+        wp_st4(b.rad + dst, out_r);
       if (put_v)
         b.hit_v[dst] = out_v;
       if (WANG)

@@ -52,8 +52,9 @@ def _same(a, b):
 def _properties_and_oracle_rows(r, cam, w, h, sqrt_spp, depth, rng_mode, shards=3, oracle_stride=33):
     """The shared body of the full-size tests.  Returns the whole image of the default kernel."""
     a = _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO)
-    # the shipping kernel is what ran (a keyed-PCG launch of >= 2e7 paths starts with its timed trial of kernel 9)
-    assert _last_kernel(r) == 8 or (rng_mode == T.RNG_PCG and _last_kernel(r) == 9)
+    # the shipping kernel is what ran (a launch of >= 2e6 independent paths starts with the trial of kernel 9 — with the
+    # reference's RNG too since the end of round 3: a single frame's pixels are 2e6 independent units at 1080p)
+    assert _last_kernel(r) in (8, 9)
     assert np.isfinite(a).all() and (a[..., 3] == 1).all() and (a[..., :3] >= 0).all()
     assert _same(a, _launch(r, cam, _ffi.KERNEL_VARIANT_AUTO))    # deterministic
     b = _launch(r, cam, 0)
