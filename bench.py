@@ -603,16 +603,19 @@ def main():
             visits_per_ray = (cnd["tlas_interior"] + cnd["blas_interior"] + cnd["tlas_leaf"] + cnd["tris_tested"]) / max(cnd["rays"], 1)
             kernel_rate = visits_per_ray * rays_per_launch / (trace_ms * 1e-3)
             if cdoc is not None and "l1_accesses" in cdoc["kernels"][ckey]:
-                # The limit the kernel actually runs into ("The third roof"): a per-lane 16-byte load is
-                # one L1 (TCP) access, and a CU serves about one per clock — the probe reaches 0.93 per clock and CU with 2,
-                # 3 or 4 loads per step alike (tools/probe_loads.py), i.e. its step rate is 1 / loads.  No figure for this
-                # in the guide: the nominal peak is 1 access per clock and CU at 2.4 GHz, the measured one the probe's.
+                # The per-lane L1 access rate ("The third roof"): a per-lane 16-byte load is one L1 (TCP)
+                # access, and a CU serves about one per clock — the probe reaches 0.93 per clock and CU with 2, 3 or 4 loads
+                # per step alike (tools/probe_loads.py).  The kernel runs NEAR that rate but is not bound by it: taking 28 %
+                # of its accesses away (the top records in LDS) bought 2-3 % (experiments/r03_lds_cache/).  Reported as a
+                # utilisation, not as the binding roof.  No figure for this in the guide: the nominal peak is 1 access per
+                # clock and CU at 2.4 GHz, the measured one the probe's.
                 acc = cdoc["kernels"][ckey]["l1_accesses"] / (trace_ms * 1e-3) / 1e9
                 roofline["l1_access"] = {"achieved": acc, "unit": "G L1 accesses/s (TCP_TOTAL_CACHE_ACCESSES of one launch / the kernel's time)",
                                          "nominal_peak": 256 * 2.4, "frac_nominal": acc / (256 * 2.4),
                                          "probe_ceiling": 4 * best / 1e9, "frac_probe": acc / (4 * best / 1e9),
                                          "note": "nominal = 256 CUs x 1 access per clock x 2.4 GHz (an assumption, not a guide figure); "
-                                                 "probe_ceiling = 4 accesses per step x the probe's step rate, measured in this run"}
+                                                 "probe_ceiling = 4 accesses per step x the probe's step rate, measured in this run; "
+                                                 "a utilisation, not the binding roof (experiments/r03_lds_cache/)"}
             roofline["gather_probe"] = {"visits_per_s": best, "kernel_visits_per_s": kernel_rate,
                                         "frac": kernel_rate / best, "record_visits_per_ray": visits_per_ray,
                                         "how": "rt_debug_probe_walk: 1024 blocks x 256 lanes, 2000 dependent 64-B record gathers per "

@@ -90,7 +90,7 @@ int rt_render(rt_ctx *ctx, const rt_render_params *params);
  * as params->accum_count + k, k = 0 .. frame_count - 1: the image is that of frame_count successive rt_render calls,
  * bit for bit.  Handing the frames over together lets the library run them side by side: (pixel, frame) pairs are
  * independent also under the reference's sequential Wang RNG, so batches of at least 2e6 of them may go through the
- * wavefront pipeline (kernel 9) — which a single frame of the reference's RNG cannot. */
+ * wavefront pipeline (kernel 9) as independent paths; within one frame of the reference's RNG only the pixels are independent. */
 int rt_render_frames(rt_ctx *ctx, const rt_render_params *params, uint32_t frame_count);
 
 /* Test hook: intersect_tlas (TLAS.slang:14-67) over an explicit ray batch.
@@ -109,15 +109,16 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);
 /* Low byte: 0 = reference-structured kernel (one lane per pixel, nested sample / bounce / traversal loops);
  * 8 = persistent wave64s with path regeneration, a resumable per-lane traversal, vote scheduling and joined
- * pair / leaf steps (the default); 9 = sample-parallel wavefront pipeline (rt_wavefront.hip: trace, shade and
- * resolve kernels over millions of path slots in HBM): its units of work are the samples of a pixel under RT_RNG_PCG
+ * pair / leaf steps; 9 = sample-parallel wavefront pipeline (rt_wavefront.hip: traversal and shading as separate
+ * phases over path slots in device memory, a resolve kernel): its units of work are the samples of a pixel under RT_RNG_PCG
  * and the FRAMES of a pixel (rt_render_frames) under the reference's sequential Wang RNG, whose samples within a frame
- * run one after the other in a slot; rt_render blocks the host for the length of a kernel-9 launch.  Higher bits are schedule knobs (rt_kernels.hip,
+ * run one after the other in a slot.  In its default, persistent mode (rt_debug_wavefront_persistent) a kernel-9
+ * launch is asynchronous like the others; in the rounds mode rt_render blocks the host for its length.  Higher bits are schedule knobs (rt_kernels.hip,
  * rt_launch_render).  All kernels give the same results bit for bit.  RT_KERNEL_VARIANT_AUTO (the state of a new
  * context) lets rt_render choose: kernel 8, except kernel 0 for a tiny scene rendered with at most 4 samples and
  * depth 3 per launch (the reference's live configuration), and except launches of at least 2e6 independent units of
- * work — pixels x frames x samples under RT_RNG_PCG (1920x1080 from 10 samples per pixel on), pixels x frames under
- * RT_RNG_WANG (rt_render_frames from 10 frames on): which of kernels 8 and 9 is faster there depends on the scene, so the first such
+ * work — pixels x frames x samples under RT_RNG_PCG (1920x1080 from one sample per pixel on), pixels x frames under
+ * RT_RNG_WANG: which of kernels 8 and 9 is faster there depends on the scene and the shape, so the first such
  * launches of a (scene, launch shape) run kernel 9 twice (the first, on freshly allocated buffers, only warms up; the
  * second is timed) and kernel 8 once (timed; rt_render waits for the three), and the following ones the faster of the
  * two.  If a later launch of the chosen kernel takes more than 1.3x longer or shorter than its trial did — the camera
@@ -131,7 +132,9 @@ int rt_reset_stats(rt_ctx *ctx);
 int rt_set_kernel_variant(rt_ctx *ctx, uint32_t variant);
 
 /* Sizing of kernel 9's HBM state (no counterpart in the reference): at most `paths_in_flight` path slots of 88 B
- * (default 2^26 = 64 Mi paths, 5.9 GB; up to 2^30 — a launch uses a sixth of its paths, at least 2^20, at most this)
+ * (default 2^26; up to 2^30 — the persistent mode uses a window of 512 slots per resident trace wave, 3.1 Mi slots =
+ * 277 MB on an MI355X, fewer waves if the budget is smaller, and falls back to the rounds below 512; the rounds mode
+ * uses a sixth of the launch's paths, at least 2^20, at most this: 64 Mi slots = 5.9 GB)
  * and `result_bytes` for the per-path sample radiances of one sample chunk (16 B per path, default 40 GiB,
  * allocated as far as a launch needs it: a 1920x1080 launch of 1024 spp in one chunk; larger launches run in chunks of
  * whole samples, each with its own thinning rounds).
