@@ -438,6 +438,7 @@ int prepare_wavefront(rt_ctx *ctx, const rt_render_params &pc, uint32_t frame_co
     ctx->wf_geom_desc.base = ctx->wf_geom.ptr;
     ctx->wf_geom_desc.pairs_off = 0;
     ctx->wf_geom_desc.tris_off = (uint32_t)pair_bytes;
+    ctx->wf_geom_desc.bytes = (uint32_t)(pair_bytes + tri_bytes);
     ctx->wf_geom_dirty = false;
   }
   return RT_OK;

@@ -36,6 +36,8 @@ struct rt_wf_geom {
   const uint8_t *base;
   uint32_t pairs_off; // byte offset of pair record 0
   uint32_t tris_off;  // byte offset of triangle 0
+  uint32_t bytes;     // pair records + triangles (the persistent mode's non-temporal state accesses pay from a scene
+                      // larger than the L2s on)
 };
 
 uint32_t rt_wf_pool_records(uint32_t cus);

@@ -398,17 +398,27 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
 // wave long after the L2 has forgotten it (768 windows per XCD against 4 MB), so caching it there only displaces node
 // records — with the persistent mode's shade phases running beside other waves' trace phases the L2 hit rate fell from
 // 65 to 57 %.  C3, 256 spp: 227.8 -> 220.6 ms with the hint on every state load and store here (on the loads and the
-// result stores only: 222.4; also on the trace phase's ray loads and hit stores: 223.0 — those stay plain).
+// result stores only: 222.4; also on the trace phase's ray loads and hit stores: 223.0 — those stay plain).  A scene
+// that fits the L2s has no node records to protect and its windows' state does come back from the L2: there the hint
+// costs 3-4 % (C1 10119 -> 9827, C2 13705 -> 13204 Mrays/s), so it is a launch argument (`nt`, wave-uniform), set for
+// scenes of more than WP_NT_SCENE_BYTES of pair records and triangles.
+#define WP_NT_SCENE_BYTES (32u << 20)
 typedef float wp_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 wp_ld4(const float4 *p) {
+__device__ __forceinline__ float4 wp_ld4(const float4 *p, bool nt) {
+  if (!nt)
+    return *p;
   wp_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wp_f4 *>(p));
   return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void wp_st4(float4 *p, float4 a) {
+__device__ __forceinline__ void wp_st4(float4 *p, float4 a, bool nt) {
+  if (!nt) {
+    *p = a;
+    return;
+  }
   wp_f4 v = {a.x, a.y, a.z, a.w};
   __builtin_nontemporal_store(v, reinterpret_cast<wp_f4 *>(p));
 }
-__device__ __forceinline__ float wp_ld1(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float wp_ld1(const float *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
 struct WpState {
   uint32_t base = 0;     // first slot of the wave's window
@@ -444,7 +454,7 @@ __device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const 
 
 template <bool WANG>
 __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_render_params &pc, const WfChunk &ch,
-                                        const rt_wf_buffers &b, WpState &wp) {
+                                        const rt_wf_buffers &b, WpState &wp, bool nt) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -489,8 +499,8 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
         rng.set_slot(0);
         camera_ray(cam, recip_sqrt_spp, x, y, sample % pc.sqrt_spp, sample / pc.sqrt_spp, rng, p);
       }
-      wp_st4(b.ray_o + dst, make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id)));
-      wp_st4(b.ray_d + dst, make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u)));
+      wp_st4(b.ray_o + dst, make_float4(p.o.x, p.o.y, p.o.z, __uint_as_float(id)), nt);
+      wp_st4(b.ray_d + dst, make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(0u)), nt);
     }
     const unsigned long long went = __ballot(go);
     fill += (uint32_t)__popcll(went);
@@ -508,7 +518,7 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
 // index of its pool record (hit_v) along.
 template <bool WANG>
 __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera_uniforms &cam, const rt_render_params &pc,
-                                         const rt_wf_buffers &b, const WfChunk &ch, WpState &wp) {
+                                         const rt_wf_buffers &b, const WfChunk &ch, WpState &wp, bool nt) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
@@ -521,12 +531,12 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
     float out_v = 0.f;
     uint32_t out_seed = 0;
     if (g0 + lane < wp.n_live) {
-      const float4 rd = wp_ld4(b.ray_d + slot);
+      const float4 rd = wp_ld4(b.ray_d + slot, nt);
       uint32_t depth = __float_as_uint(rd.w);
       const bool has_rad = (depth & WF_HAS_RAD) != 0u, has_att = (depth & WF_HAS_ATT) != 0u;
-      const float4 ro = wp_ld4(b.ray_o + slot);
-      const float4 at = has_att ? wp_ld4(b.att + slot) : make_float4(1.f, 1.f, 1.f, 0.f);
-      const float4 ra = has_rad ? wp_ld4(b.rad + slot) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 ro = wp_ld4(b.ray_o + slot, nt);
+      const float4 at = has_att ? wp_ld4(b.att + slot, nt) : make_float4(1.f, 1.f, 1.f, 0.f);
+      const float4 ra = has_rad ? wp_ld4(b.rad + slot, nt) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (WANG)
         out_seed = b.seed[slot];
       if (sums)
@@ -537,7 +547,7 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
         out_v = b.hit_v[slot], put_v = true;
       } else {
         depth &= ~(WF_HAS_RAD | WF_HAS_ATT);
-        const float4 h = wp_ld4(b.hit + slot);
+        const float4 h = wp_ld4(b.hit + slot, nt);
         const uint32_t id = __float_as_uint(ro.w);
         uint32_t x, y, entry;
         wf_pixel_of(pc, ch, id, x, y, entry);
@@ -554,7 +564,7 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
         Hit hit;
         hit.t = h.x, hit.tri = __float_as_uint(h.y), hit.inst = __float_as_uint(h.z), hit.u = h.w;
         const bool any = hit.tri != RT_INVALID_ID;
-        hit.v = any ? wp_ld1(b.hit_v + slot) : 0.f;
+        hit.v = any ? wp_ld1(b.hit_v + slot, nt) : 0.f;
         const bool scattered = shade(sc, pc.flags, any, hit, rng, p);
         ++depth;
         if (scattered && depth < pc.max_depth) {
@@ -580,22 +590,22 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
             out_fs = make_float4(sum.x, sum.y, sum.z, __uint_as_float(s_idx));
             goes_on = true;
           } else {
-            wp_st4(b.sr + id, make_float4(sum.x, sum.y, sum.z, 0.f)); // the frame's radiance
+            wp_st4(b.sr + id, make_float4(sum.x, sum.y, sum.z, 0.f), nt); // the frame's radiance
           }
         } else { // RayTracing.slang:170: the sample's radiance, summed per pixel in sample order by k_wf_resolve
-          wp_st4(b.sr + id, make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f));
+          wp_st4(b.sr + id, make_float4(p.sample_radiance.x, p.sample_radiance.y, p.sample_radiance.z, 0.f), nt);
         }
       }
     }
     const unsigned long long m_on = __ballot(goes_on);
     if (goes_on) {
       const uint32_t dst = wp.base + n_on + (uint32_t)__popcll(m_on & below);
-      wp_st4(b.ray_o + dst, out_o);
-      wp_st4(b.ray_d + dst, out_d);
+      wp_st4(b.ray_o + dst, out_o, nt);
+      wp_st4(b.ray_d + dst, out_d, nt);
       if (put_att)
-        wp_st4(b.att + dst, out_a);
+        wp_st4(b.att + dst, out_a, nt);
       if (put_rad)
-        wp_st4(b.rad + dst, out_r);
+        wp_st4(b.rad + dst, out_r, nt);
       if (put_v)
         b.hit_v[dst] = out_v;
       if (WANG)
@@ -703,6 +713,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   // PERSIST: the wave owns the window of WP_WINDOW slots at wp_base for the whole launch and alternates between
   // filling it, tracing it and shading it (wp_fill / wp_shade below)
   WpState wp;
+  const bool wp_nt = (sched_arg & 0x10000u) != 0u; // (PERSIST: non-temporal state accesses in fill and shade)
   wp.base = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * WP_WINDOW;
   wp.stripe = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
 
@@ -717,7 +728,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     return;
   do { // (PERSIST: one turn per fill / trace / shade of the window; otherwise once)
   if (PERSIST) {
-    wp_fill<WANG>(cam, pc, ch, b, wp);
+    wp_fill<WANG>(cam, pc, ch, b, wp, wp_nt);
     if (wp.n_live == 0u)
       break;
     grab_next = wp.base, grab_end = wp.base + wp.n_live;
@@ -1083,7 +1094,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     }
   }
   if (PERSIST)
-    wp_shade<WANG>(sc, cam, pc, b, ch, wp);
+    wp_shade<WANG>(sc, cam, pc, b, ch, wp, wp_nt);
   } while (PERSIST);
   count_rays(ray_counter, traced);
 }
@@ -1472,10 +1483,11 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         if (waves == 0 || waves > 0xFFFFu || (uint64_t)pblocks * pblock > b.pool_records)
           return hipErrorInvalidValue;
         const uint32_t susp = susp_lanes | ((uint32_t)waves << 16); // (one pool, no list; bits 16-31: windows)
+        const uint32_t psched = sched | (geom.bytes > WP_NT_SCENE_BYTES ? 0x10000u : 0u);
         stamp_begin(counts ? &counts->trace_ms : nullptr);
 #define RT_WF_PERSIST(MODE)                                                                                            \
-  (wang ? wf_launch_persist<MODE, true>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc)  \
-        : wf_launch_persist<MODE, false>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, sched, susp, cam, pc))
+  (wang ? wf_launch_persist<MODE, true>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
+        : wf_launch_persist<MODE, false>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc))
         e = pc.aabb_mode == RT_AABB_RCP ? RT_WF_PERSIST(RT_AABB_RCP) : RT_WF_PERSIST(RT_AABB_DIV);
 #undef RT_WF_PERSIST
         stamp_end();
