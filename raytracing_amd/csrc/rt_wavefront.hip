@@ -452,7 +452,7 @@ __device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const 
   }
 }
 
-template <bool WANG>
+template <int WANG> // 0: keyed PCG; 1: the reference's RNG at one sample per frame; 2: at more (the slot carries the frame's sum)
 __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_render_params &pc, const WfChunk &ch,
                                         const rt_wf_buffers &b, WpState &wp, bool nt) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -491,7 +491,7 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
         rng.seed = wf_wang_seed(pc, x, y, entry);
         camera_ray(cam, recip_sqrt_spp, x, y, 0u, 0u, rng, p);
         b.seed[dst] = rng.seed;
-        if (spp > 1u)
+        if (WANG == 2)
           b.fsum[dst] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
       } else {    // entry = frame * spp + sample: the absolute sample index keys the draws
         const uint32_t sample = entry % spp;
@@ -516,13 +516,13 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
 // read, and a batch's loads are complete before its stores.  Everything a path owns moves with it: ray, attenuation,
 // radiance, and — reference's RNG — its state and (spp > 1) the frame's sample sum; a suspended ray also takes the
 // index of its pool record (hit_v) along.
-template <bool WANG>
+template <int WANG>
 __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera_uniforms &cam, const rt_render_params &pc,
                                          const rt_wf_buffers &b, const WfChunk &ch, WpState &wp, bool nt) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t spp = pc.sqrt_spp * pc.sqrt_spp;
-  const bool sums = WANG && spp > 1u; // the slot carries the frame's radiance over the samples done so far
+  constexpr bool sums = WANG == 2; // the slot carries the frame's radiance over the samples done so far
   uint32_t n_on = 0;
   for (uint32_t g0 = 0; g0 < wp.n_live; g0 += 64u) {
     const uint32_t slot = wp.base + g0 + lane;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void wp_shade(const rt_dev_scene &sc, const rt_camera
           V3 sum = v3(out_fs.x, out_fs.y, out_fs.z); // (+0 at spp 1)
           uint32_t s_idx = __float_as_uint(out_fs.w);
           sum = sum + p.sample_radiance;
-          if (s_idx + 1u < spp) { // the next sample of this pixel and frame continues the RNG stream (:76-77)
+          if (sums && s_idx + 1u < spp) { // the next sample of this pixel and frame continues the RNG stream (:76-77)
             ++s_idx;
             Path np;
             camera_ray(cam, 1.f / (float)pc.sqrt_spp, x, y, s_idx % pc.sqrt_spp, s_idx / pc.sqrt_spp, rng, np);
@@ -651,7 +651,7 @@ enum : uint32_t { WT_FETCH = 0, WT_TRAVERSE = 2, WT_FINISHED = 3, WT_EXIT = 4 };
 #define WF_COOP_STRIDE 1040u
 #define WF_COOP_BYTES (4u * WF_COOP_STRIDE) // per wave
 
-template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP, int NCACHE, bool PERSIST, bool WANG>
+template <int MODE, int MINW, int BLOCK, int NLDS, bool COOP, int NCACHE, bool PERSIST, int WANG>
 __global__ void __launch_bounds__(BLOCK, MINW)
     k_wf_trace(rt_dev_scene sc, rt_wf_geom geom, rt_wf_buffers b, WfChunk ch, unsigned long long *ray_counter,
                uint32_t regen_idle, uint32_t sched_arg, uint32_t susp_arg, rt_camera_uniforms cam, rt_render_params pc) {
@@ -1330,23 +1330,29 @@ static hipError_t wf_launch_trace_shape(uint32_t blocks, hipStream_t stream, Arg
   hipLaunchKernelGGL((k_wf_trace<MODE, RT_WF_MINW, BLOCK, NLDS, false, NCACHE, false, false>), dim3(blocks), dim3(BLOCK), lds_bytes, stream, args...);
   return hipSuccess;
 }
-// the persistent mode's shape: as the trace pass for the keyed PCG RNG; for the reference's RNG, whose shade part
-// needs 86 registers, 5 waves per SIMD in workgroups of 256 lanes (5 x (16 + 10) KiB of LDS per CU).  C3, 256 frames
-// of 1 spp: 6 waves (28 spills in the shade phase) 298 ms, 5 waves 236 ms, the rounds 240 ms; the keyed PCG RNG
-// in the 5-wave shape: 236 against 228 ms.
+// The persistent mode's shapes.  The kernel's WANG parameter: 0 = keyed PCG, 1 = the reference's RNG at ONE sample per
+// frame (the reference's own sampling, Renderer.cpp:21), 2 = at more (the slot carries the frame's sample sum and the
+// shade phase may start the pixel's next camera ray).  Kinds 0 and 1 take the trace pass's shape (6 waves per SIMD,
+// 512 lanes, 320 records in LDS); kind 2, whose shade part needs 86 registers, 5 waves per SIMD in workgroups of 256
+// lanes (5 x (16 + 10) KiB of LDS per CU).  C3, 256 frames of 1 spp: one kernel for both Wang kinds at 6 waves (28 spills in
+// the shade phase) 298 ms, at 5 waves 236 ms, at 4 waves 266 ms, the rounds 240 ms; kind 1 on its own at 6 waves
+// (the next-sample code compiled out: 14 spills) 222.5 ms = 5430 Mrays/s.  The keyed PCG RNG in the 5-wave shape: 236
+// against 228 ms.
 #ifndef WP_WANG_MINW
 #define WP_WANG_MINW 5
 #endif
+#define WP_WANG_SHAPE5 2 // the kernel's WANG kind that takes the 5-wave shape: the reference's RNG at spp > 1 per frame
 #define WP_WANG_BLOCK 256
 #define WP_WANG_CACHE 160
-template <int MODE, bool WANG, typename... Args>
+template <int MODE, int WANG, typename... Args>
 static hipError_t wf_launch_persist(uint32_t blocks, hipStream_t stream, Args... args) {
-  constexpr int BLOCK = WANG ? WP_WANG_BLOCK : WF_TRACE_BLOCK, CACHE = WANG ? WP_WANG_CACHE : WF_TRACE_CACHE;
+  constexpr int BLOCK = WANG == WP_WANG_SHAPE5 ? WP_WANG_BLOCK : WF_TRACE_BLOCK, CACHE = WANG == WP_WANG_SHAPE5 ? WP_WANG_CACHE : WF_TRACE_CACHE;
   const size_t lds_bytes = (size_t)RT_WF_NLDS * BLOCK * 4 + (size_t)CACHE * 64;
-  hipLaunchKernelGGL((k_wf_trace<MODE, WANG ? WP_WANG_MINW : RT_WF_MINW, BLOCK, RT_WF_NLDS, false, CACHE, true, WANG>), dim3(blocks),
+  hipLaunchKernelGGL((k_wf_trace<MODE, WANG == WP_WANG_SHAPE5 ? WP_WANG_MINW : RT_WF_MINW, BLOCK, RT_WF_NLDS, false, CACHE, true, WANG>), dim3(blocks),
                      dim3(BLOCK), lds_bytes, stream, args...);
   return hipSuccess;
 }
+
 template <int MODE, typename... Args>
 static hipError_t wf_launch_trace(const WfTraceShape &s, uint32_t blocks, hipStream_t stream, Args... args) {
   if (s.ncache)
@@ -1473,8 +1479,10 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         // No rounds: one launch of the trace kernel in its PERSIST mode renders the chunk — every wave fills, traces
         // and shades its own window of slots until the chunk's path ids are used up.  Nothing is read back, the host
         // does not wait.
-        const uint32_t pblock = wang ? WP_WANG_BLOCK : WF_TRACE_BLOCK;
-        const uint64_t waves_max = (uint64_t)cus * (wang ? WP_WANG_MINW : RT_WF_MINW) * 4u;
+        const int wkind = !wang ? 0 : pc.sqrt_spp > 1u ? 2 : 1; // the kernel's WANG parameter
+        const bool shape5 = wkind == WP_WANG_SHAPE5;
+        const uint32_t pblock = shape5 ? WP_WANG_BLOCK : WF_TRACE_BLOCK;
+        const uint64_t waves_max = (uint64_t)cus * (shape5 ? WP_WANG_MINW : RT_WF_MINW) * 4u;
         uint64_t waves = ((uint64_t)ch.total + WP_WINDOW - 1) / WP_WINDOW;
         waves = waves < waves_max ? waves : waves_max;
         if (waves * WP_WINDOW > b.slots)
@@ -1486,8 +1494,9 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         const uint32_t psched = sched | (geom.bytes > WP_NT_SCENE_BYTES ? 0x10000u : 0u);
         stamp_begin(counts ? &counts->trace_ms : nullptr);
 #define RT_WF_PERSIST(MODE)                                                                                            \
-  (wang ? wf_launch_persist<MODE, true>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
-        : wf_launch_persist<MODE, false>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc))
+  (wkind == 2   ? wf_launch_persist<MODE, 2>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
+   : wkind == 1 ? wf_launch_persist<MODE, 1>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
+                : wf_launch_persist<MODE, 0>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc))
         e = pc.aabb_mode == RT_AABB_RCP ? RT_WF_PERSIST(RT_AABB_RCP) : RT_WF_PERSIST(RT_AABB_DIV);
 #undef RT_WF_PERSIST
         stamp_end();
