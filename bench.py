@@ -3,13 +3,15 @@
 
 Workload (N=1): dragon-class mesh (procedural stand-in, 870,400 triangles, seed
 1234 — the reference's dragon.obj is missing from its snapshot) on a ground
-plane under the sky gradient, 1920x1080, 256 spp per step (one launch of the
-path-tracing megakernel with a 16x16 stratified grid), max_depth 8, reference
-slab arithmetic (division).  `--rng pcg` (default) is the keyed PCG RNG that north_star
-names — every draw a hash of (pixel, sample, bounce, dimension) — which lets the library
-run its sample-parallel wavefront pipeline (kernel 9); `--rng wang` is the reference's
-sequential Wang hash, which admits only the megakernel (kernel 8): the default run
-measures it too and reports it under "wang_rng".  A step is one full frame; successive
+plane under the sky gradient, 1920x1080, 256 spp per step (one launch with a 16x16
+stratified grid), max_depth 8, reference slab arithmetic (division).  `--rng pcg`
+(default) is the keyed PCG RNG that north_star names — every draw a hash of (pixel,
+sample, bounce, dimension) — which lets the library run the samples of a pixel side by
+side (kernel 9: one persistent kernel in which every wave fills, traces and shades a
+window of path slots, then a resolve kernel); `--rng wang` is the reference's
+sequential Wang hash: the default run measures it too and reports it under "wang_rng" —
+as the reference samples (progressive frames of one sample per pixel, handed over as a
+batch: kernel 9 again) and as one stratified frame (the megakernel, kernel 8).  A step is one full frame; successive
 steps are successive progressive frames (RayTracing.slang:176-179).
 
 N>1 (one process per GPU, RCCL): the scene is replicated and every frame is cut

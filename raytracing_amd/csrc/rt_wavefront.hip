@@ -24,6 +24,12 @@
 // Per pixel the arithmetic, the RNG keys and the order of the radiance sum are those of k_render_v0 in PCG mode, so
 // the image is the same bit for bit.
 //
+// End of round 3: NO ROUNDS.  The kernels above run as rounds over all slots with the host between them (kept:
+// rt_debug_wavefront_persistent(ctx, 0)).  By default a launch is now ONE dispatch of k_wf_trace in its PERSIST mode —
+// every resident wave owns a window of 512 slots and fills it with new paths, traces it and shades it in a loop
+// (wp_fill / the step loop / wp_shade) — followed by k_wf_resolve; the arithmetic per path is the same, so the image is.
+// The first 320 pair records (the breadth-first top of the scene) are read from an LDS copy (NCACHE).
+//
 // Round 3: FRAME BATCHES and the reference's own RNG.  The reference reaches high sample counts by progressive frames
 // of sqrt_spp^2 (= 1) samples each, re-seeding the Wang state per (x, y, frame_index) (RayTracing.slang:71-72,
 // Renderer.cpp:21, 625, 651): the samples of ONE frame of a pixel are a sequence, but (pixel, frame) pairs are
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
 
 
 // ---------------------------------------------------------------------------
-// PERSIST mode of k_wf_trace (EXPERIMENT): no rounds.  Every resident wave owns a window of WP_WINDOW path slots for the
+// PERSIST mode of k_wf_trace: no rounds (experiments/r03_persistent/ has the measurements).  Every resident wave owns a window of WP_WINDOW path slots for the
 // whole launch and loops: fill the free positions with new paths (camera rays of whole 64-id groups, drawn from
 // striped counters), trace the window's rays (the step loop, lanes refilling from the window, stragglers suspended),
 // shade the window (one lane per slot, 64 at a time; paths that go on are written to the window's front in place).
