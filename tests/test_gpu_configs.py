@@ -169,6 +169,36 @@ def test_automatic_choice_times_both_kernels_once_per_scene_and_shape():
         r.shutdown()
 
 
+def test_kernel9_launch_returns_before_the_image_is_done():
+    """The reference's dispatch is asynchronous (Renderer.cpp:644-651).  Kernel 9 in its default, persistent mode reads
+    nothing back, so rt_render returns at once as it does for kernels 0 and 8 (it blocked for the length
+    of the launch while the host read path counters between rounds — which the rounds mode still does)."""
+    import bench, time
+    w, h = 1920, 1080
+    r = R.Renderer(w, h, device=0)
+    cam, _ = bench.build_dragon_scene(R, r)
+    r.set_option(R.OPT_MAX_DEPTH, 8)
+    r.set_option(R.OPT_RNG_MODE, T.RNG_PCG)
+    r.set_option(R.OPT_SAMPLES_PER_PIXEL, 64)
+    r.set_option(R.OPT_KERNEL_VARIANT, 9)
+    ctx = C.c_void_p(r.hip_context_handle())
+    times = {}
+    for persistent in (1, 0):
+        _ffi._check(_ffi.lib().rt_debug_wavefront_persistent(ctx, persistent))
+        r.render(cam)  # buffers of this mode allocated, code loaded
+        r.wait()
+        t0 = time.perf_counter()
+        r.render(cam)
+        t_call = time.perf_counter() - t0
+        r.wait()
+        times[persistent] = (t_call, time.perf_counter() - t0)
+    call, whole = times[1]
+    assert whole > 0.03 and call < 0.25 * whole, times  # a 64-spp launch takes about 58 ms; the call a fraction of one
+    call0, whole0 = times[0]
+    assert call0 > 0.8 * whole0, times                  # the rounds: the call IS the launch
+    r.shutdown()
+
+
 def test_c3_pcg_takes_the_wavefront_pipeline():
     """C3 with the keyed PCG RNG at 64 spp per launch: the automatic choice is kernel 9 (the sample-parallel
     wavefront pipeline, rt_wavefront.hip), and its image equals kernel 8's and — on the same 40 rows as above, at
