@@ -1510,94 +1510,93 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
           return e;
         if (counts)
           ++counts->rounds;
-        goto resolve_chunk;
-      }
-      // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
-      stamp_begin(counts ? &counts->fill_ms : nullptr);
-      if (wang)
-        hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
-      else
-        hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
-      stamp_end();
-      bool have_list = false; // the last shade pass wrote the live-slot list
-      bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
-      for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
-        // live paths after the last shade: the host decides whether another round is needed
-        if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + wf_alive_set(round), WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-          return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
-          return e;
-        uint64_t alive = 0;
-        for (uint32_t k = 0; k < WF_STRIPES; ++k)
-          alive += h_ctrl[k * WF_PAD];
-        if (alive == 0)
-          break;
-        // the next shade pass writes the live-slot list once this chunk has run out of new paths (until then every
-        // slot is refilled and the list would be all of them)
-        const bool make_list = list_below && alive < ch.slots;
-        if (have_list && !maybe_suspended && alive <= finish_paths) { // the last few: one kernel sees them through
-          uint32_t longest = 0;
+      } else {
+        // first fill: every slot starts a path (or is marked dead when the chunk has fewer paths than slots)
+        stamp_begin(counts ? &counts->fill_ms : nullptr);
+        if (wang)
+          hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
+        else
+          hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch, compact_bit);
+        stamp_end();
+        bool have_list = false; // the last shade pass wrote the live-slot list
+        bool maybe_suspended = false; // the last trace pass was allowed to suspend rays
+        for (uint32_t round = 0;; ++round) { // trace pass `round` follows shade pass `round` (the first fill is pass 0)
+          // live paths after the last shade: the host decides whether another round is needed
+          if ((e = hipMemcpyAsync(h_ctrl, b.ctrl + wf_alive_set(round), WF_STRIPES * WF_PAD * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            return e;
+          if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+            return e;
+          uint64_t alive = 0;
           for (uint32_t k = 0; k < WF_STRIPES; ++k)
-            longest = h_ctrl[k * WF_PAD] > longest ? h_ctrl[k * WF_PAD] : longest;
-          stamp_begin(counts ? &counts->finish_ms : nullptr);
-          if (wang)
-            hipLaunchKernelGGL(k_wf_finish<true>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
-                               sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+            alive += h_ctrl[k * WF_PAD];
+          if (alive == 0)
+            break;
+          // the next shade pass writes the live-slot list once this chunk has run out of new paths (until then every
+          // slot is refilled and the list would be all of them)
+          const bool make_list = list_below && alive < ch.slots;
+          if (have_list && !maybe_suspended && alive <= finish_paths) { // the last few: one kernel sees them through
+            uint32_t longest = 0;
+            for (uint32_t k = 0; k < WF_STRIPES; ++k)
+              longest = h_ctrl[k * WF_PAD] > longest ? h_ctrl[k * WF_PAD] : longest;
+            stamp_begin(counts ? &counts->finish_ms : nullptr);
+            if (wang)
+              hipLaunchKernelGGL(k_wf_finish<true>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
+                                 sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+            else
+              hipLaunchKernelGGL(k_wf_finish<false>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
+                                 sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+            stamp_end();
+            if ((e = hipGetLastError()) != hipSuccess)
+              return e;
+            if (counts)
+              counts->finished_paths += alive;
+            break;
+          }
+          // reset the trace kernel's queue heads and the counters of the NEXT shade pass (adjacent in the control block;
+          // this pass's counters stay: they are the lengths of the live-slot list)
+          if ((e = hipMemsetAsync(b.ctrl + ((round + 1u) & 1u ? WF_HEAD : WF_ALIVE0), 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t),
+                                  stream)) != hipSuccess)
+            return e;
+          // While most slots hold a path the trace pass walks the slots themselves (coalesced, no indirection; a dead
+          // slot costs a 16-byte read); once they thin out it walks the list of live slots the shade pass left, and
+          // the grid is sized by that list.
+          const bool by_list = have_list && alive * 100u < (uint64_t)ch.slots * list_below;
+          // (a short list goes out in smaller shares, down to one ray per lane: the last rounds are a matter of latency)
+          uint32_t share = full_share;
+          if (by_list && alive / (resident * (tblock / 64u)) < share)
+            share = (uint32_t)(alive / (resident * (tblock / 64u))) / 64u * 64u;
+          share = share < 64u ? 64u : share;
+          const uint64_t need = ((by_list ? alive : (uint64_t)ch.slots) + share - 1) / share; // one wave per share at least
+          const uint32_t blocks = (uint32_t)(need / (tblock / 64) + 1 < resident ? need / (tblock / 64) + 1 : resident);
+          // rays may be suspended while the rounds are full (the next round comes anyway and carries them along); once
+          // the paths thin out every ray is seen through, or the stragglers would add rounds of their own
+          const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * tblock <= b.pool_records
+                                     ? susp_lanes : 0u) | ((round & 1u) << 8) | (by_list ? 0x200u : 0u) | ((round & 1u) << 10) | (share << 16);
+          stamp_begin(counts ? &counts->trace_ms : nullptr);
+          if (pc.aabb_mode == RT_AABB_RCP)
+            RT_WF_TRACE(RT_AABB_RCP);
           else
-            hipLaunchKernelGGL(k_wf_finish<false>, dim3((longest + RT_BLOCK - 1) / RT_BLOCK, WF_STRIPES), dim3(RT_BLOCK), 0, stream,
-                               sc, cam, pc, b, ch, round, shade_blocks, d_counter);
+            RT_WF_TRACE(RT_AABB_DIV);
           stamp_end();
+          stamp_begin(counts ? &counts->shade_ms : nullptr);
+          if (wang)
+            hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                               ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
+          else
+            hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
+                               ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
+          stamp_end();
+          have_list = make_list;
           if ((e = hipGetLastError()) != hipSuccess)
             return e;
-          if (counts)
-            counts->finished_paths += alive;
-          break;
-        }
-        // reset the trace kernel's queue heads and the counters of the NEXT shade pass (adjacent in the control block;
-        // this pass's counters stay: they are the lengths of the live-slot list)
-        if ((e = hipMemsetAsync(b.ctrl + ((round + 1u) & 1u ? WF_HEAD : WF_ALIVE0), 0, 2 * WF_STRIPES * WF_PAD * sizeof(uint32_t),
-                                stream)) != hipSuccess)
-          return e;
-        // While most slots hold a path the trace pass walks the slots themselves (coalesced, no indirection; a dead
-        // slot costs a 16-byte read); once they thin out it walks the list of live slots the shade pass left, and
-        // the grid is sized by that list.
-        const bool by_list = have_list && alive * 100u < (uint64_t)ch.slots * list_below;
-        // (a short list goes out in smaller shares, down to one ray per lane: the last rounds are a matter of latency)
-        uint32_t share = full_share;
-        if (by_list && alive / (resident * (tblock / 64u)) < share)
-          share = (uint32_t)(alive / (resident * (tblock / 64u))) / 64u * 64u;
-        share = share < 64u ? 64u : share;
-        const uint64_t need = ((by_list ? alive : (uint64_t)ch.slots) + share - 1) / share; // one wave per share at least
-        const uint32_t blocks = (uint32_t)(need / (tblock / 64) + 1 < resident ? need / (tblock / 64) + 1 : resident);
-        // rays may be suspended while the rounds are full (the next round comes anyway and carries them along); once
-        // the paths thin out every ray is seen through, or the stragglers would add rounds of their own
-        const uint32_t susp = (susp_lanes && !coop && alive * 2u >= ch.slots && (uint64_t)blocks * tblock <= b.pool_records
-                                   ? susp_lanes : 0u) | ((round & 1u) << 8) | (by_list ? 0x200u : 0u) | ((round & 1u) << 10) | (share << 16);
-        stamp_begin(counts ? &counts->trace_ms : nullptr);
-        if (pc.aabb_mode == RT_AABB_RCP)
-          RT_WF_TRACE(RT_AABB_RCP);
-        else
-          RT_WF_TRACE(RT_AABB_DIV);
-        stamp_end();
-        stamp_begin(counts ? &counts->shade_ms : nullptr);
-        if (wang)
-          hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
-                             ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
-        else
-          hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shade_blocks), dim3(WF_SHADE_BLOCK), 0, stream, sc, cam, pc, b, ch,
-                             ((round + 1u) & 1u) | compact_bit | (make_list ? 0x80000000u : 0u));
-        stamp_end();
-        have_list = make_list;
-        if ((e = hipGetLastError()) != hipSuccess)
-          return e;
-        maybe_suspended = (susp & 0xFFu) != 0u;
-        if (counts) {
-          ++counts->rounds;
-          counts->list_rounds += by_list ? 1u : 0u;
+          maybe_suspended = (susp & 0xFFu) != 0u;
+          if (counts) {
+            ++counts->rounds;
+            counts->list_rounds += by_list ? 1u : 0u;
+          }
         }
       }
     }
-  resolve_chunk:
     stamp_begin(counts ? &counts->resolve_ms : nullptr);
     hipLaunchKernelGGL(k_wf_resolve, dim3((uint32_t)((tile_slots + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, pc,
                        b, ch, (uint32_t)tile_slots, accum, first ? 1u : 0u, last ? 1u : 0u);
