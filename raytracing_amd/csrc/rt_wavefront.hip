@@ -386,14 +386,13 @@ __global__ void __launch_bounds__(WF_SHADE_BLOCK)
     b.live[(size_t)stripe * ch.list_span + s_at + before + (uint32_t)__popcll(lm & below)] = dst;
 }
 
-
 // ---------------------------------------------------------------------------
-// PERSIST mode of k_wf_trace: no rounds (experiments/r03_persistent/ has the measurements).  Every resident wave owns a window of WP_WINDOW path slots for the
-// whole launch and loops: fill the free positions with new paths (camera rays of whole 64-id groups, drawn from
-// striped counters), trace the window's rays (the step loop, lanes refilling from the window, stragglers suspended),
-// shade the window (one lane per slot, 64 at a time; paths that go on are written to the window's front in place).
-// The path state never leaves the wave, so it lives in L2 / the Infinity Cache instead of streaming through HBM
-// every round, there is no kernel boundary per round and the host never waits.
+// PERSIST mode of k_wf_trace: no rounds (experiments/r03_persistent/ has the measurements).  Every resident wave owns a
+// window of WP_WINDOW path slots for the whole launch and loops: fill the free positions with new paths (camera rays
+// of whole 64-id groups, drawn from striped counters), trace the window's rays (the step loop, lanes refilling from
+// the window, stragglers suspended), shade the window (one lane per slot, 64 at a time; paths that go on are written
+// to the window's front in place).  The path state never leaves its wave (277 MB for the whole GPU instead of the
+// rounds' 5.9 GB streaming through HBM twice per round), there is no kernel boundary per round and the host never waits.
 // ---------------------------------------------------------------------------
 // slots per wave.  C3, 256 spp, ms per launch (full frame / one rank's eighth): 128 254.4 / 32.7, 256 232.7 / 30.4,
 // 512 226.6 / 29.9, 1024 225.2 / 31.7 — against 242.5 / 36.4 for the rounds (experiments/r03_persistent/)
