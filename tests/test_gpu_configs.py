@@ -146,11 +146,11 @@ def test_automatic_choice_times_both_kernels_once_per_scene_and_shape():
     """Keyed PCG, 1920x1080, 64 spp: a context that was given no kernel runs kernel 9 on the first two launches of a
     shape (warm-up, timed), kernel 8 on the third and the faster of the two afterwards; a new scene or shape starts over;
     all the same bits.
-    On the closed Cornell box the megakernel beats kernel 9's ROUNDS by a quarter (the mode without
-    rounds, the default, is level with it there: either may win, the choice must only be kept), under the open sky of
-    the teapot scene the pipeline wins in both modes."""
+    On the closed Cornell box the megakernel and kernel 9 are within a few per cent of each other at this size (with
+    kernel 9's rounds as without them: either may win, the choice must only be kept); under the open sky of the teapot
+    scene the pipeline wins by a factor of two."""
     w, h = 1920, 1080
-    for scene, persistent, winner in (("cornell.json", False, 8), ("cornell.json", True, None), ("teapot.json", True, 9)):
+    for scene, persistent, winner in (("cornell.json", False, None), ("cornell.json", True, None), ("teapot.json", True, 9)):
         r = R.Renderer(w, h, device=0)
         _ffi._check(_ffi.lib().rt_debug_wavefront_persistent(C.c_void_p(r.hip_context_handle()), 1 if persistent else 0))
         cam, _ = r.load_scene_file(os.path.join(SCENES, scene))
