@@ -11,7 +11,7 @@ from tests.test_host_parity import _cornell_via_product
 W, H, FRAMES = 1280, 720, 300
 r = _cornell_via_product(device=0, w=W, h=H)
 cam = R.Camera((0, 0.75, 1.5), (0, 0.75, -1), (0, 1, 0), 90.0)
-for variant in (_ffi.KERNEL_VARIANT_AUTO, 8, 0):
+for variant in (_ffi.KERNEL_VARIANT_AUTO, 8, 0, 9):
     r.set_option(R.OPT_KERNEL_VARIANT, variant)
     for _ in range(20):
         r.render(cam)
