@@ -662,6 +662,36 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
         c.close()
 
 
+@pytest.mark.parametrize("kind,cam_pos", [("tiny_vertex", (0, 0.75, 1.5)), ("stretched", (0, 1e25, 1.5)), ("squashed", (1e-30, 0.75, 1.5))])
+def test_edge_scenes_every_kernel_rng_and_mode(ctx, kind, cam_pos):
+    """Scenes outside the fast slab test's preconditions, whose images are full of infinities and NaNs (a NaN's sign and
+    payload depend on operand order, so this also pins code generation): every kernel, both RNGs (the reference's at one
+    and at four samples per frame: kernel 9's kinds 1 and 2), kernel 9 with and without rounds, both slab tests —
+    the oracle's bits."""
+    sc = S.edge_scene(kind).build()
+    ctx.upload_scene(sc)
+    w, h = 72, 40
+    cam = O.camera_uniforms(cam_pos, (0, 0.75, -1), (0, 1, 0), 90.0, w, h)
+    ctx.set_camera(cam)
+    ctx.resize(w, h)
+    try:
+        for rng_mode in (T.RNG_PCG, T.RNG_WANG):
+            for sqrt_spp in (1, 2):
+                for mode in (T.AABB_DIV, T.AABB_RCP):
+                    p = O.render_params(w, h, 0, sqrt_spp, 4, rng_mode=rng_mode, aabb_mode=mode)
+                    want = O.render(sc, cam, p, nthreads=8)
+                    for variant, persistent in ((0, True), (8, True), (9, True), (9, False)):
+                        ctx.set_kernel_variant(variant)
+                        ctx.wavefront_persistent(persistent)
+                        ctx.clear_accum()
+                        ctx.render(p)
+                        got = ctx.read_accum(w, h)
+                        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rng_mode, sqrt_spp, mode, variant, persistent)
+    finally:
+        ctx.wavefront_persistent(True)
+        ctx.set_kernel_variant(_ffi.KERNEL_VARIANT_AUTO)
+
+
 @pytest.mark.parametrize("coop", [0, 1])
 def test_wavefront_deep_stack_and_edge_scenes(ctx, coop):
     """Kernel 9's trace kernel keeps 16 stack entries in LDS: the 38-instance chain drives it to 37; scenes outside the
