@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Low-spp launches of the persistent kernel: effect of the regeneration threshold."""
+"""Low-spp launches of the persistent megakernel (kernel 8): effect of the regeneration threshold (kernel 0 beside it)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -37,6 +37,6 @@ for name, r, cam in (("cornell", rc, camc), ("teapot", rt, camt), ("dragon", rd,
         row = []
         ms0, _ = run(r, cam, 0, spp, depth, max(2, 32 // spp))
         for idle in (16, 32, 48, 56):
-            ms, mr = run(r, cam, 5 | (idle << 8), spp, depth, max(2, 32 // spp))
+            ms, mr = run(r, cam, 8 | (idle << 8), spp, depth, max(2, 32 // spp))
             row.append(f"idle{idle}: {ms:7.3f}")
-        print(f"{name:8s} spp {spp:2d} depth {depth}  v0 {ms0:7.3f} | v5 " + " ".join(row))
+        print(f"{name:8s} spp {spp:2d} depth {depth}  v0 {ms0:7.3f} | v8 " + " ".join(row))
