@@ -450,8 +450,12 @@ __device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const 
     if (lane == 0)
       k = atomicAdd(b.ctrl + WF_HEAD + wp.stripe * WF_PAD, 1u);
     k = (uint32_t)__builtin_amdgcn_readlane((int)k, 0);
-    const uint64_t g = (uint64_t)wp.stripe + (uint64_t)k * WF_STRIPES;
-    if (g < groups)
+    // an eighth of the groups (a band of the image) per class of workgroups that share an XCD (blockIdx % 8): stripe
+    // s = 8 * class + j hands out groups class * per + j, + 8, ...
+    const uint32_t per = (groups + 7u) / 8u, x = wp.stripe >> 3;
+    const uint64_t end = (uint64_t)(x + 1u) * per < groups ? (uint64_t)(x + 1u) * per : groups;
+    const uint64_t g = (uint64_t)x * per + (wp.stripe & 7u) + (uint64_t)k * 8u;
+    if (g < end)
       return (uint32_t)g;
     wp.used_seen |= 1ull << wp.stripe;
   }
@@ -720,7 +724,8 @@ __global__ void __launch_bounds__(BLOCK, MINW)
   WpState wp;
   const bool wp_nt = (sched_arg & 0x10000u) != 0u; // (PERSIST: non-temporal state accesses in fill and shade)
   wp.base = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * WP_WINDOW;
-  wp.stripe = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % WF_STRIPES;
+  static_assert(WF_STRIPES == 64, "eight stripes for each of the eight XCD classes");
+  wp.stripe = (blockIdx.x % 8u) * 8u + ((blockIdx.x / 8u) * (BLOCK / 64) + (threadIdx.x >> 6)) % 8u;
 
   const uint32_t w_pair = (sched_arg & 0xFu) ? (sched_arg & 0xFu) : 1u;
   const uint32_t w_leaf = ((sched_arg >> 4) & 0xFu) ? ((sched_arg >> 4) & 0xFu) : 2u;
