@@ -161,12 +161,19 @@ int rt_set_wavefront_budget(rt_ctx *ctx, uint32_t paths_in_flight, uint64_t resu
  * up; the host reads nothing back, so rt_render returns at once as it does for kernels 0 and 8.  0 = the rounds of
  * rounds 2 and 3: a trace and a shade kernel per round over all slots, the host reading the live-path count between
  * them (rt_render then blocks until the image is complete); _tuning's list_percent, share and finish_paths and the
- * counts of _counts belong to that mode.  The image does not depend on it. */
+ * counts of _counts belong to that mode.  The image does not depend on it.
+ * _bands: how the persistent mode deals the launch's paths to the GPU's eight XCDs.  0 = interleaved, every XCD works
+ * on the same tiles at the same time; 1 = each XCD (each class of workgroups that share one) works through its own
+ * eighth of the frame, so that the eight L2s hold eight different parts of the scene; 2 = the default: bands for
+ * launches of at least 1e8 paths over a scene of more than 32 MB of records, where they gain about 1 % (they cost small
+ * launches up to 30 % and scenes that fit the L2s 4 %).  The reference's RNG at more than one sample per frame is
+ * always interleaved.  The image does not depend on it. */
 int rt_debug_wavefront_tuning(rt_ctx *ctx, uint32_t suspend_lanes, uint32_t list_percent, uint32_t share,
                               uint32_t finish_paths);
 int rt_debug_wavefront_compaction(rt_ctx *ctx, uint32_t enable);
 int rt_debug_wavefront_record_cache(rt_ctx *ctx, uint32_t enable);
 int rt_debug_wavefront_persistent(rt_ctx *ctx, uint32_t enable);
+int rt_debug_wavefront_bands(rt_ctx *ctx, uint32_t mode);
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths);
 

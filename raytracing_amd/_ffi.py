@@ -19,7 +19,7 @@ SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_update_instances", "rt_set_camera",
     "rt_resize", "rt_bind_accum", "rt_clear_accum", "rt_render", "rt_render_frames", "rt_trace_closest",
     "rt_trace_closest_device", "rt_read_accum", "rt_accum_device_ptr", "rt_sync",
-    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_compaction", "rt_debug_wavefront_record_cache", "rt_debug_wavefront_persistent", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_debug_wavefront_timing", "rt_build_tlas_cluster",
+    "rt_get_stats", "rt_reset_stats", "rt_set_stream", "rt_set_kernel_variant", "rt_set_wavefront_budget", "rt_debug_probe_walk", "rt_debug_fast_div", "rt_debug_wavefront_tuning", "rt_debug_wavefront_compaction", "rt_debug_wavefront_record_cache", "rt_debug_wavefront_persistent", "rt_debug_wavefront_bands", "rt_debug_wavefront_counts", "rt_debug_fail_wavefront_allocs", "rt_debug_wavefront_timing", "rt_build_tlas_cluster",
     "rt_build_tlas_cluster_noalloc",
     "rt_last_error_string",
     "rt_device_count",
@@ -101,6 +101,7 @@ def lib():
     L.rt_debug_wavefront_compaction.argtypes = [vp, u32]
     L.rt_debug_wavefront_record_cache.argtypes = [vp, u32]
     L.rt_debug_wavefront_persistent.argtypes = [vp, u32]
+    L.rt_debug_wavefront_bands.argtypes = [vp, u32]
     L.rt_debug_wavefront_counts.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.rt_debug_fail_wavefront_allocs.argtypes = [vp, u32]
     L.rt_debug_wavefront_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
@@ -251,6 +252,9 @@ class HipContext:
 
     def wavefront_persistent(self, enable=True):
         _check(lib().rt_debug_wavefront_persistent(self._h, 1 if enable else 0))
+
+    def wavefront_bands(self, mode=2):
+        _check(lib().rt_debug_wavefront_bands(self._h, mode))
 
     def wavefront_record_cache(self, enable=True):
         _check(lib().rt_debug_wavefront_record_cache(self._h, 1 if enable else 0))

@@ -1054,6 +1054,16 @@ int rt_debug_wavefront_record_cache(rt_ctx *ctx, uint32_t enable) {
   return RT_OK;
 }
 
+int rt_debug_wavefront_bands(rt_ctx *ctx, uint32_t mode) {
+  if (!ctx)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_bands: NULL context");
+  if (mode > 2u)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wavefront_bands: mode is 0 (never), 1 (always) or 2 (by launch and scene size)");
+  ctx->wf_tuning.bands = mode == 2u ? 0xFFFFFFFFu : mode;
+  ctx->tune = rt_ctx::Tune{}; // the measured kernel choice was made with the old setting
+  return RT_OK;
+}
+
 int rt_debug_wavefront_counts(rt_ctx *ctx, uint64_t *rounds, uint64_t *list_rounds, uint64_t *suspended_rays,
                               uint64_t *finished_paths) {
   if (!ctx || !rounds || !list_rounds || !suspended_rays || !finished_paths)

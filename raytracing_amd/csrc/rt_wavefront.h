@@ -60,6 +60,9 @@ struct rt_wf_tuning {
                                         // in a loop (0 = rounds of trace and shade kernels with the host between them; default on)
   uint32_t record_cache = 0xFFFFFFFFu;  // the trace kernel keeps the first pair records (the breadth-first top of the scene)
                                         // in LDS, workgroups of 512 lanes (0 = every record through the L1, 256 lanes; default on)
+  uint32_t bands = 0xFFFFFFFFu;         // persistent mode: each class of workgroups that share an XCD works through its own
+                                        // eighth of the frame (0 = never, 1 = always; default: launches of 1e8 paths or more
+                                        // over a scene of more than 32 MB, rt_wavefront.hip wp_draw_group)
 };
 struct rt_wf_counts { // statistics, summed over launches
   uint64_t rounds = 0;      // trace + shade rounds

@@ -436,7 +436,24 @@ struct WpState {
   uint32_t ids_left = 1;
 };
 
-// the next group of 64 path ids (one 8x8 tile at one entry), or WP_NO_GROUP: stripe s hands out groups s, s + 64, ...
+// the next group of 64 path ids (one 8x8 tile at one entry), or WP_NO_GROUP.  The 64 striped counters are eight per
+// class of workgroups that share an XCD and with it an L2 (blockIdx % 8; MI355X_MICROARCH: blocks are dealt round-robin
+// over the XCDs).  Two ways to deal the groups to the classes, chosen per launch:
+//  * interleaved (BANDS false): stripe s hands out groups s, s + 64, ... — every class works on the same tiles at the
+//    same time (an eighth of their samples each) and the launch's cost spreads evenly whatever the image looks like;
+//  * BANDS: class c works through its own eighth of the groups, a band of tile rows (stripe 8 c + j: groups
+//    c * per + j, + 8, ...), so the eight L2s hold the records of eight parts of the scene instead of eight copies of
+//    one: C3 at 256 spp 220.1 -> 217.7 ms (L2 hit rate 58.1 -> 59.3 %, FETCH_SIZE 498 -> 464 GB).  But bands of
+//    unequal cost only level out by waves moving on to the next class's stripes, and a launch with few groups per wave
+//    has nothing left to move to: C3 at 1 / 4 / 16 spp 2.9 -> 4.0 / 6.0 -> 6.8 / 16.1 -> 16.4 ms; and a scene that fits
+//    the L2s has nothing to gain (C2, 256 spp: 51.9 -> 54.0 ms).  Pieces of 1 ... 2048 tiles dealt round-robin to the
+//    classes (tools/sweep_band_tiles.sh on an experimental build) were no better than interleaved.
+// So bands are for launches of at least WP_BANDS_MIN_PATHS paths over a scene of more than WP_NT_SCENE_BYTES.  The
+// choice is a template parameter because as a launch argument it cost what it gained (one more scalar kept across
+// the step loop: 220.4 against 218.4 ms).
+#define WP_BANDS_MIN_PATHS 100000000ull
+#define WP_KIND_BANDS 4 // added to the kernel's WANG parameter (kinds 0 and 1)
+template <bool BANDS>
 __device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const WfChunk &ch, WpState &wp) {
   const uint32_t groups = ch.total >> 6;
   const uint32_t lane = threadIdx.x & 63u;
@@ -450,18 +467,22 @@ __device__ __forceinline__ uint32_t wp_draw_group(const rt_wf_buffers &b, const 
     if (lane == 0)
       k = atomicAdd(b.ctrl + WF_HEAD + wp.stripe * WF_PAD, 1u);
     k = (uint32_t)__builtin_amdgcn_readlane((int)k, 0);
-    // an eighth of the groups (a band of the image) per class of workgroups that share an XCD (blockIdx % 8): stripe
-    // s = 8 * class + j hands out groups class * per + j, + 8, ...
-    const uint32_t per = (groups + 7u) / 8u, x = wp.stripe >> 3;
-    const uint64_t end = (uint64_t)(x + 1u) * per < groups ? (uint64_t)(x + 1u) * per : groups;
-    const uint64_t g = (uint64_t)x * per + (wp.stripe & 7u) + (uint64_t)k * 8u;
-    if (g < end)
-      return (uint32_t)g;
+    if (BANDS) {
+      const uint32_t per = (groups + 7u) / 8u, c = wp.stripe >> 3;
+      const uint64_t end = (uint64_t)(c + 1u) * per < groups ? (uint64_t)(c + 1u) * per : groups;
+      const uint64_t g = (uint64_t)c * per + (wp.stripe & 7u) + (uint64_t)k * 8u;
+      if (g < end)
+        return (uint32_t)g;
+    } else {
+      const uint64_t g = (uint64_t)wp.stripe + (uint64_t)k * WF_STRIPES;
+      if (g < groups)
+        return (uint32_t)g;
+    }
     wp.used_seen |= 1ull << wp.stripe;
   }
 }
 
-template <int WANG> // 0: keyed PCG; 1: the reference's RNG at one sample per frame; 2: at more (the slot carries the frame's sum)
+template <int WANG, bool BANDS> // 0: keyed PCG; 1: the reference's RNG at one sample per frame; 2: at more (the slot carries the frame's sum)
 __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_render_params &pc, const WfChunk &ch,
                                         const rt_wf_buffers &b, WpState &wp, bool nt) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -473,7 +494,7 @@ __device__ __forceinline__ void wp_fill(const rt_camera_uniforms &cam, const rt_
     if (wp.pend_mask == 0ull) {
       if (!wp.ids_left)
         break;
-      const uint32_t g = wp_draw_group(b, ch, wp);
+      const uint32_t g = wp_draw_group<BANDS>(b, ch, wp);
       if (g == WP_NO_GROUP) {
         wp.ids_left = 0u;
         break;
@@ -738,7 +759,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     return;
   do { // (PERSIST: one turn per fill / trace / shade of the window; otherwise once)
   if (PERSIST) {
-    wp_fill<WANG>(cam, pc, ch, b, wp, wp_nt);
+    wp_fill<(WANG & 3), (WANG & WP_KIND_BANDS) != 0>(cam, pc, ch, b, wp, wp_nt);
     if (wp.n_live == 0u)
       break;
     grab_next = wp.base, grab_end = wp.base + wp.n_live;
@@ -1104,7 +1125,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
     }
   }
   if (PERSIST)
-    wp_shade<WANG>(sc, cam, pc, b, ch, wp, wp_nt);
+    wp_shade<(WANG & 3)>(sc, cam, pc, b, ch, wp, wp_nt);
   } while (PERSIST);
   count_rays(ray_counter, traced);
 }
@@ -1501,13 +1522,19 @@ hipError_t rt_launch_render_wavefront(const rt_dev_scene &sc, const rt_wf_geom &
         if (waves == 0 || waves > 0xFFFFu || (uint64_t)pblocks * pblock > b.pool_records)
           return hipErrorInvalidValue;
         const uint32_t susp = susp_lanes | ((uint32_t)waves << 16); // (one pool, no list; bits 16-31: windows)
-        const uint32_t psched = sched | (geom.bytes > WP_NT_SCENE_BYTES ? 0x10000u : 0u);
+        const bool big_scene = geom.bytes > WP_NT_SCENE_BYTES;
+        const uint32_t psched = sched | (big_scene ? 0x10000u : 0u);
+        const bool bands = wkind != 2 && (tune.bands == 0xFFFFFFFFu ? big_scene && ch.total >= WP_BANDS_MIN_PATHS
+                                                                  : tune.bands != 0u); // (wp_draw_group)
         stamp_begin(counts ? &counts->trace_ms : nullptr);
+#define RT_WF_PERSIST_KIND(MODE, KIND)                                                                                 \
+  wf_launch_persist<MODE, KIND>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc)
 #define RT_WF_PERSIST(MODE)                                                                                            \
-  (wkind == 2   ? wf_launch_persist<MODE, 2>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
-   : wkind == 1 ? wf_launch_persist<MODE, 1>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc) \
-                : wf_launch_persist<MODE, 0>(pblocks, stream, sc, geom, b, ch, d_counter, regen_idle, psched, susp, cam, pc))
+  (wkind == 2   ? RT_WF_PERSIST_KIND(MODE, 2)                                                                          \
+   : wkind == 1 ? (bands ? RT_WF_PERSIST_KIND(MODE, 1 | WP_KIND_BANDS) : RT_WF_PERSIST_KIND(MODE, 1))                  \
+                : (bands ? RT_WF_PERSIST_KIND(MODE, 0 | WP_KIND_BANDS) : RT_WF_PERSIST_KIND(MODE, 0)))
         e = pc.aabb_mode == RT_AABB_RCP ? RT_WF_PERSIST(RT_AABB_RCP) : RT_WF_PERSIST(RT_AABB_DIV);
+#undef RT_WF_PERSIST_KIND
 #undef RT_WF_PERSIST
         stamp_end();
         if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)

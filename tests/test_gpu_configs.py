@@ -314,12 +314,19 @@ def test_c3_kernel9_at_the_bench_shape_equals_the_oracle():
         assert _same(got[rows], want[rows]), spp
     rounds, list_rounds, suspended, finished = _ffi_counts(r)
     assert (rounds, list_rounds, finished) == (2, 0, 0) and suspended > 0  # two launches without rounds; windows' last rays suspended
-    # the same 256-spp launch through the trace / shade rounds of rounds 2 and 3 (suspension, live-slot list, finishing kernel)
-    _ffi._check(_ffi.lib().rt_debug_wavefront_persistent(C.c_void_p(r.hip_context_handle()), 0))
-    _ffi._check(_ffi.lib().rt_reset_stats(C.c_void_p(r.hip_context_handle())))
+    # the same 256-spp launch with the paths dealt to the XCDs the other way: launches of this size take bands of the
+    # frame per XCD (rt_debug_wavefront_bands), here interleaved
+    ctx = C.c_void_p(r.hip_context_handle())
     r.set_option(R.OPT_SAMPLES_PER_PIXEL, 256)
-    got = _launch(r, cam, 9)
     rows, want = _oracle_rows(r, cam, w, h, 16, depth, T.RNG_PCG, 67)
+    _ffi._check(_ffi.lib().rt_debug_wavefront_bands(ctx, 0))
+    got = _launch(r, cam, 9)
+    assert _same(got[rows], want[rows])
+    _ffi._check(_ffi.lib().rt_debug_wavefront_bands(ctx, 2))
+    # and through the trace / shade rounds of rounds 2 and 3 (suspension, live-slot list, finishing kernel)
+    _ffi._check(_ffi.lib().rt_debug_wavefront_persistent(ctx, 0))
+    _ffi._check(_ffi.lib().rt_reset_stats(ctx))
+    got = _launch(r, cam, 9)
     assert _same(got[rows], want[rows])
     rounds, list_rounds, suspended, finished = _ffi_counts(r)
     assert rounds > 2 and suspended > 0 and finished > 0

@@ -643,7 +643,9 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
             q.accum_count = f
             O.render(sc, cam, q, want, counters=cn, nthreads=8)
         images, rays = [], []
-        for on, cache, persistent in ((True, True, False), (False, False, False), (True, False, False), (True, True, True)):
+        for on, cache, persistent, bands in ((True, True, False, 2), (False, False, False, 2), (True, False, False, 2), (True, True, True, 0),
+                                             (True, True, True, 1)):
+            c.wavefront_bands(bands)  # persistent mode: interleaved / a band of the frame per XCD (by default: large launches only)
             c.wavefront_compaction(on)
             c.wavefront_record_cache(cache)  # the trace kernel's LDS copy of the top records (and its 512-lane workgroups)
             c.wavefront_persistent(persistent)  # no rounds: every wave fills, traces and shades its own window (the default)
@@ -656,8 +658,10 @@ def test_wavefront_compaction_moves_paths_not_results(rng, spp_side, frames, slo
         assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
         assert np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
         assert np.array_equal(images[0].view(np.uint32), images[3].view(np.uint32))
+        assert np.array_equal(images[0].view(np.uint32), images[4].view(np.uint32))
         _same_image(images[0], want)
-        assert rays[0] == rays[1] == rays[2] == rays[3] == cn.rays
+        assert rays[0] == rays[1] == rays[2] == rays[3] == rays[4] == cn.rays
+        c.wavefront_bands(2)
     finally:
         c.close()
 

@@ -128,6 +128,8 @@ def test_random_scene_kernel9_round_scheduling_is_invisible(seed):
         c.wavefront_tuning(*tuning)
         persistent = bool(rng.integers(0, 2))  # no rounds (the default; budgets below one window of 512 slots fall back) / rounds
         c.wavefront_persistent(persistent)
+        bands = int(rng.integers(0, 2))  # the persistent mode's paths interleaved over the XCDs / a band of the frame per XCD
+        c.wavefront_bands(bands)
         c.reset_stats()
         cn = O.Counters()
         want = np.zeros((h, w, 4), np.float32)
@@ -136,7 +138,7 @@ def test_random_scene_kernel9_round_scheduling_is_invisible(seed):
             c.render(p)
             O.render(sc, cam, p, want, counters=cn, nthreads=8)
         got = c.read_accum(w, h)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, tuning, persistent, sqrt_spp, depth, aabb)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, tuning, persistent, bands, sqrt_spp, depth, aabb)
         assert c.stats().rays_traced == cn.rays, (seed, tuning, persistent)
     finally:
         c.close()

@@ -46,6 +46,7 @@ for seed in range(500, 500 + cases):
             c.wavefront_record_cache(rep != 1 or bool(rng.integers(0, 2)))  # top records in LDS (default) / all through the L1
             persistent = rep == 0 or bool(rng.integers(0, 2))  # no rounds (default) / trace and shade rounds
             c.wavefront_persistent(persistent)
+            c.wavefront_bands(2 if rep == 0 else int(rng.integers(0, 2)))  # persistent mode: by launch size / interleaved / bands
             c.clear_accum()
             c.reset_stats()
             c.render_frames(p, nf)
