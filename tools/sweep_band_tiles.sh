@@ -1,5 +1,5 @@
 #!/bin/bash
-# Sweep of RT_WF_BAND_TILES (experimental builds only: tiles per piece of the frame that one XCD class of the persistent
+# Sweep of RT_WF_BAND_TILES (a build with experiments/r03_persistent/band_pieces.patch applied: tiles per piece of the frame that one XCD class of the persistent
 # kernel works through): tools/sweep_band_tiles.sh LIB T1 T2 ...
 lib=$1; shift
 cp "$lib" raytracing_amd/librt_hip.so || exit 1
