@@ -1363,7 +1363,8 @@ static hipError_t wf_launch_trace_shape(uint32_t blocks, hipStream_t stream, Arg
 }
 // The persistent mode's shapes.  The kernel's WANG parameter: 0 = keyed PCG, 1 = the reference's RNG at ONE sample per
 // frame (the reference's own sampling, Renderer.cpp:21), 2 = at more (the slot carries the frame's sample sum and the
-// shade phase may start the pixel's next camera ray).  Kinds 0 and 1 take the trace pass's shape (6 waves per SIMD,
+// shade phase may start the pixel's next camera ray); WP_KIND_BANDS added to kind 0 or 1 = the groups of path ids dealt
+// to the XCD classes in bands (wp_draw_group).  Kinds 0 and 1 take the trace pass's shape (6 waves per SIMD,
 // 512 lanes, 320 records in LDS); kind 2, whose shade part needs 86 registers, 5 waves per SIMD in workgroups of 256
 // lanes (5 x (16 + 10) KiB of LDS per CU).  C3, 256 frames of 1 spp: one kernel for both Wang kinds at 6 waves (28 spills in
 // the shade phase) 298 ms, at 5 waves 236 ms, at 4 waves 266 ms, the rounds 240 ms; kind 1 on its own at 6 waves
