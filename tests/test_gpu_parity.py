@@ -586,6 +586,7 @@ def test_wavefront_suspended_rays_live_slot_list_and_finisher(scene, suspend, li
         c.set_wavefront_budget(8192, 1 << 30)  # 8 Ki slots for 93 K / 35 K paths: full rounds, then the thinning ones
         c.wavefront_tuning(suspend, listp, share, finish)
         c.wavefront_persistent(persistent)
+        c.wavefront_bands(1 if persistent and suspend != 8 else 2)  # (persistent: a band of the frame per XCD, also on row groups)
         c.set_camera(cam)
         c.resize(w, h)
         c.reset_stats()
